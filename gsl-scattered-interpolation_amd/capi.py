@@ -1,0 +1,511 @@
+"""ctypes bindings of include/gsl_sinterp.h and include/gsl_sinterp_hip.h.
+
+Mirrors the C structs (LP64) and wraps the entry points with numpy / torch
+friendly helpers.  Device pointers are plain integers (``tensor.data_ptr()``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+GSL_SUCCESS, GSL_FAILURE = 0, -1
+GSL_EDOM, GSL_EFAULT, GSL_EINVAL, GSL_EFAILED, GSL_ENOMEM = 1, 3, 4, 5, 8
+GSL_EBADLEN, GSL_ENOTSQR, GSL_EUNIMPL = 19, 20, 24
+RBF_GAUSSIAN, RBF_TPS = 0, 1
+TREE_DEFAULT, TREE_NOSTANDARDIZE, TREE_ISOSCALE = 0, 1, 2
+TREE_RECORD_BYTES, TREE_LEAFTAB_BYTES = 64, 32
+
+
+def library_path():
+    return os.path.join(_HERE, "libgsl_sinterp.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load libgsl_sinterp.so; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no pure-Python or CPU fallback)")
+        _lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        _declare(_lib)
+        _lib.gsl_set_error_handler_off()
+    return _lib
+
+
+# ------------------------------------------------------------------ structs
+class gsl_block(C.Structure):
+    _fields_ = [("size", C.c_size_t), ("data", C.POINTER(C.c_double))]
+
+
+class gsl_vector(C.Structure):
+    _fields_ = [("size", C.c_size_t), ("stride", C.c_size_t), ("data", C.POINTER(C.c_double)),
+                ("block", C.POINTER(gsl_block)), ("owner", C.c_int)]
+
+
+class gsl_matrix(C.Structure):
+    _fields_ = [("size1", C.c_size_t), ("size2", C.c_size_t), ("tda", C.c_size_t),
+                ("data", C.POINTER(C.c_double)), ("block", C.POINTER(gsl_block)), ("owner", C.c_int)]
+
+
+class gsl_permutation(C.Structure):
+    _fields_ = [("size", C.c_size_t), ("data", C.POINTER(C.c_size_t))]
+
+
+class simplex_tree_node(C.Structure):
+    _fields_ = [("points", C.c_int), ("links", C.c_int), ("type", C.c_uint, 2)]
+
+
+class simplex_tree_accel(C.Structure):
+    _fields_ = [("simplex_matrix", C.POINTER(gsl_matrix)), ("perm", C.POINTER(gsl_permutation)),
+                ("coords", C.POINTER(gsl_vector)), ("current_simplex", C.c_int)]
+
+
+class simplex_tree(C.Structure):
+    _fields_ = [
+        ("n_simplexes", C.c_int), ("max_simplexes", C.c_int), ("simplexes", C.POINTER(simplex_tree_node)),
+        ("n_pidx", C.c_int), ("max_pidx", C.c_int), ("pidx", C.POINTER(C.c_int)),
+        ("n_links", C.c_int), ("max_links", C.c_int), ("links", C.POINTER(C.c_int)),
+        ("seed_points", C.POINTER(gsl_matrix)), ("n_points", C.c_int), ("max_points", C.c_int), ("dim", C.c_int),
+        ("shift", C.POINTER(gsl_vector)), ("scale", C.POINTER(gsl_vector)),
+        ("min", C.POINTER(gsl_vector)), ("max", C.POINTER(gsl_vector)),
+        ("shuffle", C.POINTER(gsl_permutation)), ("accel", C.POINTER(simplex_tree_accel)),
+        ("new_simplexes", C.POINTER(C.c_int)), ("old_neighbors1", C.POINTER(C.c_int)),
+        ("old_neighbors2", C.POINTER(C.c_int)), ("left_out", C.POINTER(C.c_int)),
+        ("tmp_points1", C.POINTER(C.c_int)), ("tmp_vec1", C.POINTER(gsl_vector)),
+        ("tmp_vec2", C.POINTER(gsl_vector)), ("tmp_mat", C.POINTER(gsl_matrix)),
+    ]
+
+
+class gsl_sinterp(C.Structure):
+    _fields_ = [("type", C.c_void_p), ("dim", C.c_size_t), ("size", C.c_size_t), ("device", C.c_int),
+                ("shape", C.c_double), ("init_flags", C.c_int), ("rng", C.c_void_p), ("state", C.c_void_p)]
+
+
+_vp, _i, _sz, _d = C.c_void_p, C.c_int, C.c_size_t, C.c_double
+_pd, _pi = C.POINTER(C.c_double), C.POINTER(C.c_int)
+_pm, _pv, _pt = C.POINTER(gsl_matrix), C.POINTER(gsl_vector), C.POINTER(simplex_tree)
+
+# name -> (restype, argtypes); this table is also what tests check the .so exports
+SIGNATURES = {
+    # --- include/gsl_sinterp_hip.h
+    "gsl_sinterp_hip_device_count": (_i, []),
+    "gsl_sinterp_hip_ctx_create": (_i, [C.POINTER(_vp), _i, _vp]),
+    "gsl_sinterp_hip_ctx_destroy": (None, [_vp]),
+    "gsl_sinterp_hip_sync": (_i, [_vp]),
+    "gsl_sinterp_hip_last_error": (C.c_char_p, [_vp]),
+    "gsl_sinterp_hip_malloc": (_i, [_vp, C.POINTER(_vp), _sz]),
+    "gsl_sinterp_hip_free": (_i, [_vp, _vp]),
+    "gsl_sinterp_hip_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "gsl_sinterp_hip_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "gsl_sinterp_hip_timer_start": (_i, [_vp]),
+    "gsl_sinterp_hip_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "gsl_sinterp_hip_tree_pack": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _pd, _vp]),
+    "gsl_sinterp_hip_tree_bind": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "gsl_sinterp_hip_bary_eval": (_i, [_vp, _i, _vp, _vp, _pd, _vp, _sz, _sz, _vp, _vp, C.POINTER(C.c_longlong)]),
+    "gsl_sinterp_hip_rbf_fill": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz]),
+    "gsl_sinterp_hip_cholesky_decomp1": (_i, [_vp, _sz, _vp, _sz, _pi]),
+    "gsl_sinterp_hip_cholesky_svx": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "gsl_sinterp_hip_lu_decomp": (_i, [_vp, _sz, _vp, _sz, _vp, _pi]),
+    "gsl_sinterp_hip_lu_svx": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "gsl_sinterp_hip_rbf_eval": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp]),
+    "gsl_sinterp_hip_synth_unit": (_i, [_vp, C.c_uint64, C.c_uint64, _d, _d, _vp, _sz]),
+    # --- include/gsl_sinterp.h part 1 (reference symbols)
+    "simplex_tree_node_alloc": (_i, [_pt]),
+    "simplex_tree_alloc": (_pt, [_i, _i]),
+    "simplex_tree_init": (_i, [_pt, _pm, _pv, _pv, _i, _vp]),
+    "simplex_tree_free": (None, [_pt]),
+    "simplex_tree_accel_alloc": (_vp, [_i]),
+    "simplex_tree_accel_free": (None, [_vp]),
+    "point_in_simplex": (_i, [_pt, _i, _i]),
+    "find_leaf": (_i, [_pt, _pm, _pv, _vp]),
+    "_find_leaf": (_i, [_pt, _i, _pm, _pv, _vp]),
+    "insert_point": (_i, [_pt, _i, _pm, _pv, _vp]),
+    "in_hypersphere": (_i, [_pt, _i, _pm, _i, _vp]),
+    "in_hypersphere_points": (_i, [_pt, _pi, _pm, _i, _vp]),
+    "calculate_hypersphere": (_i, [_pt, _i, _pm, _pv, _pd, _vp]),
+    "calculate_hypersphere_points": (_i, [_pt, _pi, _pm, _pv, _pd, _vp]),
+    "calculate_bary_coords": (_i, [_pt, _i, _pm, _pv, _vp]),
+    "contains_point": (_i, [_pt, _i, _pm, _pv, _vp]),
+    "interp_point": (_d, [_pt, _i, _pm, _pv, _pv, _vp]),
+    "delaunay": (_i, [_pt, _i, _pm, _i, _vp]),
+    # --- part 2
+    "simplex_tree_device_alloc": (_vp, [_pt, _pm, _i]),
+    "simplex_tree_device_free": (None, [_vp]),
+    "simplex_tree_device_set_response": (_i, [_vp, _pv]),
+    "simplex_tree_device_eval_many": (_i, [_vp, _pm, _pv, _pi]),
+    "simplex_tree_device_eval_resident": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "simplex_tree_device_ctx": (_vp, [_vp]),
+    # --- part 3
+    "gsl_sinterp_alloc": (C.POINTER(gsl_sinterp), [_vp, _sz, _sz]),
+    "gsl_sinterp_set_device": (_i, [C.POINTER(gsl_sinterp), _i]),
+    "gsl_sinterp_set_shape": (_i, [C.POINTER(gsl_sinterp), _d]),
+    "gsl_sinterp_set_tree_options": (_i, [C.POINTER(gsl_sinterp), _i, _vp]),
+    "gsl_sinterp_init": (_i, [C.POINTER(gsl_sinterp), _pm, _pv]),
+    "gsl_sinterp_name": (C.c_char_p, [C.POINTER(gsl_sinterp)]),
+    "gsl_sinterp_min_size": (C.c_uint, [C.POINTER(gsl_sinterp)]),
+    "gsl_sinterp_eval_e": (_i, [C.POINTER(gsl_sinterp), _pv, _pd]),
+    "gsl_sinterp_eval": (_d, [C.POINTER(gsl_sinterp), _pv]),
+    "gsl_sinterp_eval_many": (_i, [C.POINTER(gsl_sinterp), _pm, _pv, _pi]),
+    "gsl_sinterp_eval_resident": (_i, [C.POINTER(gsl_sinterp), _vp, _sz, _sz, _vp, _vp]),
+    "gsl_sinterp_get_weights": (_i, [C.POINTER(gsl_sinterp), _pv]),
+    "gsl_sinterp_free": (None, [C.POINTER(gsl_sinterp)]),
+    # --- compat slice used by the bindings
+    "gsl_set_error_handler_off": (_vp, []),
+    "gsl_rng_alloc": (_vp, [_vp]),
+    "gsl_rng_set": (None, [_vp, C.c_ulong]),
+    "gsl_rng_free": (None, [_vp]),
+    "gsl_rng_get": (C.c_ulong, [_vp]),
+    "gsl_rng_uniform_int": (C.c_ulong, [_vp, C.c_ulong]),
+}
+DATA_SYMBOLS = ["gsl_sinterp_rbf_gaussian", "gsl_sinterp_rbf_tps", "gsl_sinterp_linear_simplex",
+                "gsl_rng_mt19937", "gsl_rng_default"]
+
+
+def _declare(L):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+def _ptr(symbol):
+    """value of an exported `const T *symbol` variable"""
+    return C.c_void_p.in_dll(lib(), symbol).value
+
+
+# ------------------------------------------------------------------ views
+def as_matrix(a):
+    """gsl_matrix view of a 2-D float64 numpy array (row stride honoured)."""
+    assert a.dtype == np.float64 and a.ndim == 2 and a.strides[1] == 8
+    m = gsl_matrix()
+    m.size1, m.size2, m.tda = a.shape[0], a.shape[1], a.strides[0] // 8
+    m.data = a.ctypes.data_as(_pd)
+    m.block, m.owner = None, 0
+    m._keep = a
+    return m
+
+
+def as_vector(a):
+    assert a.dtype == np.float64 and a.ndim == 1
+    v = gsl_vector()
+    v.size, v.stride = a.shape[0], (a.strides[0] // 8 if a.shape[0] > 1 else 1)
+    v.data = a.ctypes.data_as(_pd)
+    v.block, v.owner = None, 0
+    v._keep = a
+    return v
+
+
+class GslError(RuntimeError):
+    def __init__(self, status, what=""):
+        super().__init__(f"GSL status {status} {what}")
+        self.status = status
+
+
+def check(status, ctx=None):
+    if status != GSL_SUCCESS:
+        msg = lib().gsl_sinterp_hip_last_error(ctx).decode() if ctx else ""
+        raise GslError(status, msg)
+
+
+# ------------------------------------------------------------------ HIP context
+class HipContext:
+    """gsl_sinterp_hip_ctx bound to one device and (optionally) torch's current stream."""
+
+    def __init__(self, device=0, stream=None):
+        L = lib()
+        if L.gsl_sinterp_hip_device_count() <= 0:
+            raise RuntimeError("no HIP device visible: the gfx950 kernels cannot run (no CPU fallback exists)")
+        self._h = C.c_void_p()
+        st = L.gsl_sinterp_hip_ctx_create(C.byref(self._h), device, stream)
+        if st != GSL_SUCCESS:
+            raise GslError(st, "gsl_sinterp_hip_ctx_create")
+        self.device = device
+
+    @classmethod
+    def on_torch_stream(cls, device=0):
+        import torch
+        torch.cuda.set_device(device)
+        return cls(device, C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            lib().gsl_sinterp_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib().gsl_sinterp_hip_sync(self._h), self._h)
+
+    # thin wrappers: every pointer argument is an int device address
+    def tree_pack(self, n_nodes, d_type, d_pidx, d_links, n_points, d_points, geom, d_records):
+        g = np.ascontiguousarray(geom, dtype=np.float64)
+        check(lib().gsl_sinterp_hip_tree_pack(self._h, n_nodes, d_type, d_pidx, d_links, n_points, d_points,
+                                              g.ctypes.data_as(_pd), d_records), self._h)
+
+    def tree_bind(self, n_nodes, d_pidx, n_points, d_response, d_leaftab):
+        check(lib().gsl_sinterp_hip_tree_bind(self._h, n_nodes, d_pidx, n_points, d_response, d_leaftab), self._h)
+
+    def bary_eval(self, n_nodes, d_records, d_leaftab, scale, d_targets, m, ttda, d_values, d_leaf=None,
+                  count_outside=False):
+        s = np.ascontiguousarray(scale, dtype=np.float64)
+        cnt = C.c_longlong(0)
+        st = lib().gsl_sinterp_hip_bary_eval(self._h, n_nodes, d_records, d_leaftab, s.ctypes.data_as(_pd), d_targets,
+                                             m, ttda, d_values, d_leaf, C.byref(cnt) if count_outside else None)
+        if st not in (GSL_SUCCESS, GSL_EDOM):
+            check(st, self._h)
+        return cnt.value
+
+    def rbf_fill(self, kind, eps, d_x, n, dim, xtda, d_phi, lda):
+        check(lib().gsl_sinterp_hip_rbf_fill(self._h, kind, eps, d_x, n, dim, xtda, d_phi, lda), self._h)
+
+    def cholesky_decomp1(self, n, d_a, lda):
+        info = C.c_int(0)
+        st = lib().gsl_sinterp_hip_cholesky_decomp1(self._h, n, d_a, lda, C.byref(info))
+        return st, info.value
+
+    def cholesky_svx(self, n, d_llt, lda, d_x):
+        check(lib().gsl_sinterp_hip_cholesky_svx(self._h, n, d_llt, lda, d_x), self._h)
+
+    def lu_decomp(self, n, d_a, lda, d_perm):
+        sg = C.c_int(0)
+        check(lib().gsl_sinterp_hip_lu_decomp(self._h, n, d_a, lda, d_perm, C.byref(sg)), self._h)
+        return sg.value
+
+    def lu_svx(self, n, d_lu, lda, d_perm, d_x):
+        return lib().gsl_sinterp_hip_lu_svx(self._h, n, d_lu, lda, d_perm, d_x)
+
+    def rbf_eval(self, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s):
+        check(lib().gsl_sinterp_hip_rbf_eval(self._h, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s), self._h)
+
+    def synth_unit(self, seed, first, offset, span, d_out, count):
+        check(lib().gsl_sinterp_hip_synth_unit(self._h, seed, first, offset, span, d_out, count), self._h)
+
+    def timer_start(self):
+        check(lib().gsl_sinterp_hip_timer_start(self._h), self._h)
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        check(lib().gsl_sinterp_hip_timer_stop(self._h, C.byref(ms)), self._h)
+        return ms.value
+
+
+# ------------------------------------------------------------------ host tree
+class Rng:
+    """gsl_rng (mt19937) from the library's compat slice."""
+
+    def __init__(self, seed=0):
+        self._h = lib().gsl_rng_alloc(_ptr("gsl_rng_mt19937"))
+        lib().gsl_rng_set(self._h, seed)
+
+    def close(self):
+        if self._h:
+            lib().gsl_rng_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SimplexTree:
+    """The reference's simplex_tree_* API (host, 2-D) over numpy arrays."""
+
+    def __init__(self, dim, n_points):
+        self._t = lib().simplex_tree_alloc(dim, n_points)
+        if not self._t:
+            raise GslError(GSL_EUNIMPL, "simplex_tree_alloc")
+        self.data = None
+        self._mat = None
+
+    def init(self, data=None, vmin=None, vmax=None, flags=0, rng=None):
+        self.data = data
+        self._mat = as_matrix(data) if data is not None else None
+        mn = as_vector(np.ascontiguousarray(vmin, dtype=np.float64)) if vmin is not None else None
+        mx = as_vector(np.ascontiguousarray(vmax, dtype=np.float64)) if vmax is not None else None
+        return lib().simplex_tree_init(self._t, C.byref(self._mat) if self._mat is not None else None,
+                                       C.byref(mn) if mn is not None else None,
+                                       C.byref(mx) if mx is not None else None, flags,
+                                       rng._h if rng is not None else None)
+
+    def set_data(self, data):
+        self.data = data
+        self._mat = as_matrix(data)
+
+    @property
+    def c(self):
+        return self._t.contents
+
+    def _m(self):
+        return C.byref(self._mat) if self._mat is not None else None
+
+    def find_leaf(self, point):
+        p = np.ascontiguousarray(point, dtype=np.float64)
+        return lib().find_leaf(self._t, self._m(), C.byref(as_vector(p)), None)
+
+    def insert_point(self, leaf):
+        return lib().insert_point(self._t, leaf, self._m(), None, None)
+
+    def in_hypersphere(self, node, idx):
+        return lib().in_hypersphere(self._t, node, self._m(), idx, None)
+
+    def contains_point(self, node, point):
+        p = np.ascontiguousarray(point, dtype=np.float64)
+        return lib().contains_point(self._t, node, self._m(), C.byref(as_vector(p)), None)
+
+    def interp_point(self, leaf, response, point):
+        p = np.ascontiguousarray(point, dtype=np.float64)
+        r = as_vector(response) if response is not None else None
+        return lib().interp_point(self._t, leaf, self._m(), C.byref(r) if r is not None else None,
+                                  C.byref(as_vector(p)), None)
+
+    # flat copies of the DAG arrays
+    @property
+    def n_nodes(self):
+        return self.c.n_simplexes
+
+    def arrays(self):
+        t = self.c
+        n = t.n_simplexes
+        nodes = np.ctypeslib.as_array(C.cast(t.simplexes, C.POINTER(C.c_int)), (n, 3)).copy()
+        types = (nodes[:, 2] & 3).astype(np.int32)
+        pidx = np.ctypeslib.as_array(t.pidx, (3 * n,)).copy().astype(np.int32)
+        links = np.ctypeslib.as_array(t.links, (3 * n,)).copy().astype(np.int32)
+        assert (nodes[:, 0] == 3 * np.arange(n)).all() and (nodes[:, 1] == 3 * np.arange(n)).all()
+        return types, pidx, links
+
+    def shuffle(self):
+        t = self.c
+        return np.ctypeslib.as_array(t.shuffle.contents.data, (max(t.max_points, 1),)).copy()[: t.n_points]
+
+    def geom(self):
+        t = self.c
+        sp = t.seed_points.contents
+        seed = np.ctypeslib.as_array(sp.data, (3, sp.tda))[:, :2].copy().reshape(-1)
+        sh = np.array([t.shift.contents.data[0], t.shift.contents.data[1]])
+        sc = np.array([t.scale.contents.data[0], t.scale.contents.data[1]])
+        return np.concatenate([seed, sh, sc])
+
+    def device_alloc(self, device=0):
+        h = lib().simplex_tree_device_alloc(self._t, self._m(), device)
+        if not h:
+            raise GslError(GSL_EFAILED, "simplex_tree_device_alloc")
+        return DeviceTree(h)
+
+    def close(self):
+        if self._t:
+            lib().simplex_tree_free(self._t)
+            self._t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceTree:
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+    def set_response(self, response):
+        return lib().simplex_tree_device_set_response(self._h, C.byref(as_vector(response)))
+
+    def eval_many(self, targets, want_leaf=True):
+        m = targets.shape[0]
+        vals = np.empty(m, dtype=np.float64)
+        leaf = np.empty(m, dtype=np.int32) if want_leaf else None
+        st = lib().simplex_tree_device_eval_many(self._h, C.byref(as_matrix(targets)), C.byref(as_vector(vals)),
+                                                 leaf.ctypes.data_as(_pi) if want_leaf else None)
+        return st, vals, leaf
+
+    def eval_resident(self, d_targets, m, ttda, d_values, d_leaf):
+        return lib().simplex_tree_device_eval_resident(self._h, d_targets, m, ttda, d_values, d_leaf)
+
+    def close(self):
+        if self._h:
+            lib().simplex_tree_device_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ facade
+class Sinterp:
+    TYPES = {"gaussian": "gsl_sinterp_rbf_gaussian", "tps": "gsl_sinterp_rbf_tps",
+             "linear_simplex": "gsl_sinterp_linear_simplex"}
+
+    def __init__(self, kind, dim, size, device=0):
+        self._p = lib().gsl_sinterp_alloc(_ptr(self.TYPES[kind]), dim, size)
+        if not self._p:
+            raise GslError(GSL_EINVAL, "gsl_sinterp_alloc")
+        lib().gsl_sinterp_set_device(self._p, device)
+        self._rng = None
+
+    def set_shape(self, eps):
+        return lib().gsl_sinterp_set_shape(self._p, eps)
+
+    def set_tree_options(self, flags, rng):
+        self._rng = rng
+        return lib().gsl_sinterp_set_tree_options(self._p, flags, rng._h if rng is not None else None)
+
+    def init(self, x, f):
+        return lib().gsl_sinterp_init(self._p, C.byref(as_matrix(x)), C.byref(as_vector(f)))
+
+    def name(self):
+        return lib().gsl_sinterp_name(self._p).decode()
+
+    def eval_e(self, y):
+        out = C.c_double(0)
+        st = lib().gsl_sinterp_eval_e(self._p, C.byref(as_vector(np.ascontiguousarray(y, dtype=np.float64))),
+                                      C.byref(out))
+        return st, out.value
+
+    def eval_many(self, y, want_leaf=False):
+        m = y.shape[0]
+        s = np.empty(m, dtype=np.float64)
+        leaf = np.empty(m, dtype=np.int32) if want_leaf else None
+        st = lib().gsl_sinterp_eval_many(self._p, C.byref(as_matrix(y)), C.byref(as_vector(s)),
+                                         leaf.ctypes.data_as(_pi) if want_leaf else None)
+        return st, s, leaf
+
+    def eval_resident(self, d_y, m, ytda, d_s, d_leaf=None):
+        return lib().gsl_sinterp_eval_resident(self._p, d_y, m, ytda, d_s, d_leaf)
+
+    def weights(self):
+        w = np.empty(self._p.contents.size, dtype=np.float64)
+        st = lib().gsl_sinterp_get_weights(self._p, C.byref(as_vector(w)))
+        return st, w
+
+    def close(self):
+        if self._p:
+            lib().gsl_sinterp_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

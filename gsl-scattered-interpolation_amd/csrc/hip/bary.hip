@@ -1,0 +1,276 @@
+/*
+ * bary.hip -- barycentric evaluation over the host-built Delaunay history DAG.
+ * Compiled with -ffp-contract=off: every fp64 *, -, / below is a separately
+ * rounded IEEE operation in the reference's order, so located leaves and
+ * values are bit-identical to the CPU path.
+ *
+ * Replaces, for M targets at once (reference file:line):
+ *   find_leaf / _find_leaf        interpolation/linear_simplex.c:331-402
+ *   contains_point                interpolation/linear_simplex.c:653-676
+ *   calculate_bary_coords         interpolation/linear_simplex.c:607-651
+ *     gsl_linalg_LU_decomp N=2    linalg/lu.c:59-124   (done once per node: tree_pack)
+ *     gsl_linalg_LU_svx           linalg/lu.c:166-201, cblas/source_trsv_r.h:33-79
+ *   interp_point                  interpolation/linear_simplex.c:678-711
+ *
+ * HBM layout: one 64-byte record per DAG node so that a containment test is a
+ * single aligned 64-byte gather (the reference re-gathers three vertices and
+ * refactors the 2x2 system on every visit):
+ *     x0[2]   raw coordinates of the node's LAST vertex
+ *     u00,u01,l10,u11   the pivoted 2x2 LU of the standardised edge matrix
+ *     child[3]          links (children when internal, neighbours when leaf)
+ *     meta              bits 0-1 node type, bit 2 rows swapped, bit 3 singular,
+ *                       bits 4-5 number of children
+ * plus a 32-byte per-node table {f(v0), f(v1), f(v2), seed mask} bound to one
+ * response column.
+ */
+#include "common.h"
+#include <math.h>
+
+struct __attribute__((aligned(64))) NodeRec {
+  double x0, x1;
+  double u00, u01, l10, u11;
+  int child[3];
+  int meta;
+};
+static_assert(sizeof(NodeRec) == GSL_SINTERP_TREE_RECORD_BYTES, "record size");
+
+struct __attribute__((aligned(32))) LeafRec {
+  double f[3];
+  int mask; /* bit i set: vertex i is a data point (not a cage seed) */
+  int pad;
+};
+static_assert(sizeof(LeafRec) == GSL_SINTERP_TREE_LEAFTAB_BYTES, "leaf table size");
+
+#define META_TYPE(m) ((m) & 3)
+#define META_SWAPPED(m) (((m) >> 2) & 1)
+#define META_SINGULAR(m) (((m) >> 3) & 1)
+#define META_NCHILD(m) (((m) >> 4) & 3)
+
+struct Geom { double seed[6]; double shift[2]; double scale[2]; };
+
+/* ------------------------------------------------------------------------ */
+__global__ void tree_pack_kernel(int n_nodes, const int *__restrict__ type, const int *__restrict__ pidx,
+                                 const int *__restrict__ links, int n_points, const double *__restrict__ points,
+                                 Geom g, NodeRec *__restrict__ rec)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_nodes) return;
+  double v[3][2];
+  for (int i = 0; i < 3; i++) {
+    int id = pidx[3 * k + i];
+    if (id < 0) { v[i][0] = g.seed[2 * (-id - 1)]; v[i][1] = g.seed[2 * (-id - 1) + 1]; }
+    else if (id < n_points) { v[i][0] = points[2 * id]; v[i][1] = points[2 * id + 1]; }
+    else { v[i][0] = v[i][1] = 0.0; }
+  }
+  const double s0 = g.scale[0], s1 = g.scale[1], h0 = g.shift[0], h1 = g.shift[1];
+  /* linear_simplex.c:622-635 */
+  const double xv0 = s0 * (v[2][0] - h0);
+  const double xv1 = s1 * (v[2][1] - h1);
+  double m00 = s0 * (v[0][0] - h0) - xv0;
+  double m01 = s0 * (v[1][0] - h0) - xv0;
+  double m10 = s1 * (v[0][1] - h1) - xv1;
+  double m11 = s1 * (v[1][1] - h1) - xv1;
+  /* lu.c:82-119 at N=2 */
+  int swapped = fabs(m10) > fabs(m00);
+  if (swapped) { double t = m00; m00 = m10; m10 = t; t = m01; m01 = m11; m11 = t; }
+  double l10 = m10, u11 = m11;
+  if (m00 != 0.0) { l10 = m10 / m00; u11 = m11 - l10 * m01; }
+  int singular = (m00 == 0) || (u11 == 0);           /* linear_simplex_util.h:14-26 */
+
+  const int t = type[k];
+  const int nchild = t == 1 ? 3 : (t == 0 ? 0 : 2);   /* linear_simplex.h:67-80 */
+  NodeRec r;
+  r.x0 = v[2][0]; r.x1 = v[2][1];
+  r.u00 = m00; r.u01 = m01; r.l10 = l10; r.u11 = u11;
+  r.child[0] = links[3 * k]; r.child[1] = links[3 * k + 1]; r.child[2] = links[3 * k + 2];
+  r.meta = (t & 3) | (swapped << 2) | (singular << 3) | (nchild << 4);
+  rec[k] = r;
+}
+
+__global__ void tree_bind_kernel(int n_nodes, const int *__restrict__ pidx, int n_points,
+                                 const double *__restrict__ response, LeafRec *__restrict__ tab)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_nodes) return;
+  LeafRec r;
+  r.mask = 0; r.pad = 0;
+  for (int i = 0; i < 3; i++) {
+    int id = pidx[3 * k + i];
+    if (id >= 0 && id < n_points) { r.f[i] = response[id]; r.mask |= 1 << i; }
+    else r.f[i] = 0.0;
+  }
+  tab[k] = r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* coords <- U^-1 L^-1 P ((y - x0) * scale)   (linear_simplex.c:644-649)      */
+__device__ __forceinline__ void solve_node(const NodeRec &r, double y0, double y1, double s0, double s1,
+                                           double &c0, double &c1)
+{
+  double b0 = (y0 - r.x0) * s0;
+  double b1 = (y1 - r.x1) * s1;
+  const bool sw = META_SWAPPED(r.meta);
+  double t0 = sw ? b1 : b0;
+  double t1 = sw ? b0 : b1;
+  t1 -= r.l10 * t0;
+  t1 = t1 / r.u11;
+  t0 -= r.u01 * t1;
+  t0 = t0 / r.u00;
+  c0 = t0; c1 = t1;
+}
+
+__device__ __forceinline__ bool inside_unit(double c0, double c1)
+{
+  double tot = 0;
+  tot += c0;
+  if ((c0 < 0) || (c0 > 1)) return false;
+  tot += c1;
+  if ((c1 < 0) || (c1 > 1)) return false;
+  if ((tot < 0) || (tot > 1)) return false;
+  return true;
+}
+
+__device__ __forceinline__ double violation(double c0, double c1)
+{
+  double worst = 0, tot = 0;
+  tot += c0;
+  if ((c0 < 0) && (-c0 > worst)) worst = -c0;
+  else if ((c0 > 1) && (c0 - 1 > worst)) worst = c0 - 1;
+  tot += c1;
+  if ((c1 < 0) && (-c1 > worst)) worst = -c1;
+  else if ((c1 > 1) && (c1 - 1 > worst)) worst = c1 - 1;
+  if ((tot < 0) && (-tot > worst)) worst = -tot;
+  else if ((tot > 1) && (tot - 1 > worst)) worst = tot - 1;
+  return worst;
+}
+
+__device__ __forceinline__ NodeRec load_rec(const NodeRec *__restrict__ rec, int k)
+{
+  /* four 16-byte loads of one aligned 64-byte line */
+  const double2 *p = reinterpret_cast<const double2 *>(rec + k);
+  double2 a = p[0], b = p[1], c = p[2];
+  int4 d = *reinterpret_cast<const int4 *>(p + 3);
+  NodeRec r;
+  r.x0 = a.x; r.x1 = a.y; r.u00 = b.x; r.u01 = b.y; r.l10 = c.x; r.u11 = c.y;
+  r.child[0] = d.x; r.child[1] = d.y; r.child[2] = d.z; r.meta = d.w;
+  return r;
+}
+
+__global__ void __launch_bounds__(256)
+bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, double s0, double s1,
+                 const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
+                 int *__restrict__ leaf_out, unsigned long long *__restrict__ n_outside)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
+    /* coords persist across tests exactly like accel->coords in the reference */
+    double c0 = 0, c1 = 0;
+    NodeRec cur = load_rec(rec, 0);
+    bool in_cage = false;
+    if (!META_SINGULAR(cur.meta)) { solve_node(cur, y0, y1, s0, s1, c0, c1); in_cage = inside_unit(c0, c1); }
+    if (!in_cage) {                                     /* linear_simplex.c:341-347 (q7: no abort) */
+      values[k] = __builtin_nan("");
+      if (leaf_out) leaf_out[k] = -1;
+      atomicAdd(n_outside, 1ULL);
+      continue;
+    }
+    int node = 0;
+    int guard = 0;
+    while (META_TYPE(cur.meta) != 0 && guard++ < 4096) { /* depth is O(log N); bound the walk */
+      const int nc = META_NCHILD(cur.meta);
+      int best = 0, next = -1;
+      double best_worst = -1;
+      NodeRec nrec = cur;
+      for (int i = 0; i < nc; i++) {
+        const int ch = cur.child[i];
+        bool hit = false;
+        if (ch > 0 && ch < n_nodes) {
+          NodeRec cr = load_rec(rec, ch);
+          if (!META_SINGULAR(cr.meta)) { solve_node(cr, y0, y1, s0, s1, c0, c1); hit = inside_unit(c0, c1); }
+          if (hit) { next = ch; nrec = cr; break; }
+        }
+        double worst = violation(c0, c1);
+        if ((best_worst < 0) || (worst < best_worst)) { best_worst = worst; best = i; }
+      }
+      if (next < 0) {                                   /* rounding fallback, linear_simplex.c:398-400 */
+        next = cur.child[best];
+        if (next <= 0 || next >= n_nodes) break;
+        nrec = load_rec(rec, next);
+      }
+      node = next;
+      cur = nrec;
+    }
+    /* interp_point recomputes the coordinates in the final leaf */
+    if (!META_SINGULAR(cur.meta)) solve_node(cur, y0, y1, s0, s1, c0, c1);
+    const LeafRec lr = tab[node];
+    double tot = 0, interp = 0;
+    tot += c0;
+    if (lr.mask & 1) interp += c0 * lr.f[0];
+    tot += c1;
+    if (lr.mask & 2) interp += c1 * lr.f[1];
+    if (lr.mask & 4) interp += (1 - tot) * lr.f[2];
+    values[k] = interp;
+    if (leaf_out) leaf_out[k] = node;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+extern "C" int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type, const int *d_pidx,
+                                         const int *d_links, int n_points, const double *d_points,
+                                         const double *h_geom, void *d_records)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, n_nodes > 0 && n_points >= 0, ST_EINVAL);
+  REQUIRE(ctx, d_type && d_pidx && d_links && h_geom && d_records, ST_EFAULT);
+  REQUIRE(ctx, ((uintptr_t)d_records & 63) == 0, ST_EINVAL);
+  Geom g;
+  for (int i = 0; i < 6; i++) g.seed[i] = h_geom[i];
+  g.shift[0] = h_geom[6]; g.shift[1] = h_geom[7];
+  g.scale[0] = h_geom[8]; g.scale[1] = h_geom[9];
+  hipLaunchKernelGGL(tree_pack_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, n_nodes, d_type, d_pidx,
+                     d_links, n_points, d_points, g, (NodeRec *)d_records);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_tree_bind(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_pidx, int n_points,
+                                         const double *d_response, void *d_leaftab)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, n_nodes > 0 && n_points >= 0, ST_EINVAL);
+  REQUIRE(ctx, d_pidx && d_leaftab && (d_response || n_points == 0), ST_EFAULT);
+  REQUIRE(ctx, ((uintptr_t)d_leaftab & 31) == 0, ST_EINVAL);
+  hipLaunchKernelGGL(tree_bind_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, n_nodes, d_pidx,
+                     n_points, d_response, (LeafRec *)d_leaftab);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_records,
+                                         const void *d_leaftab, const double *h_scale, const double *d_targets,
+                                         size_t m, size_t ttda, double *d_values, int *d_leaf,
+                                         long long *h_n_outside)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, n_nodes > 0 && ttda >= 2, ST_EINVAL);
+  REQUIRE(ctx, d_records && d_leaftab && h_scale && (m == 0 || (d_targets && d_values)), ST_EFAULT);
+  if (h_n_outside) *h_n_outside = 0;
+  if (m == 0) return ST_SUCCESS;
+  unsigned long long *d_count = (unsigned long long *)ctx->d_scratch;
+  HIP_OK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+  size_t blocks = (m + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(bary_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
+                     (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], d_targets, m, ttda,
+                     d_values, d_leaf, d_count);
+  LAUNCH_CHECK(ctx);
+  if (h_n_outside) {
+    unsigned long long cnt = 0;
+    HIP_OK(ctx, hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    *h_n_outside = (long long)cnt;
+    if (cnt) return sinterp_fail(ctx, ST_EDOM, "bary_eval: target(s) outside the caging simplex", hipSuccess, __FILE__, __LINE__);
+  }
+  return ST_SUCCESS;
+}

@@ -1,0 +1,67 @@
+/*
+ * common.h -- shared by the HIP translation units behind include/gsl_sinterp_hip.h.
+ */
+#ifndef SINTERP_HIP_COMMON_H
+#define SINTERP_HIP_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "gsl_sinterp_hip.h"
+
+/* GSL status codes used here (include/gsl_sinterp_compat.h, err/gsl_errno.h:40-74) */
+enum { ST_SUCCESS = 0, ST_FAILURE = -1, ST_EDOM = 1, ST_EFAULT = 3, ST_EINVAL = 4, ST_EFAILED = 5, ST_ENOMEM = 8,
+       ST_EBADLEN = 19 };
+
+struct gsl_sinterp_hip_ctx {
+  int device;
+  hipStream_t stream;
+  int owns_stream;
+  hipEvent_t ev0, ev1;
+  void *d_scratch;          /* small persistent scratch: counters / info words */
+  size_t scratch_bytes;
+  void *d_work;             /* growable workspace (factorisations) */
+  size_t work_bytes;
+  char err[512];
+};
+
+static inline int sinterp_fail(gsl_sinterp_hip_ctx *ctx, int status, const char *what, hipError_t e,
+                               const char *file, int line)
+{
+  if (ctx)
+    snprintf(ctx->err, sizeof ctx->err, "%s: %s (%s:%d)", what, e == hipSuccess ? "invalid argument" : hipGetErrorString(e),
+             file, line);
+  return status;
+}
+
+#define HIP_OK(ctx, call)                                                               \
+  do {                                                                                  \
+    hipError_t _e = (call);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return sinterp_fail(ctx, _e == hipErrorOutOfMemory ? ST_ENOMEM : ST_EFAILED, #call, _e, __FILE__, __LINE__); \
+  } while (0)
+
+#define REQUIRE(ctx, cond, status)                                                      \
+  do {                                                                                  \
+    if (!(cond)) return sinterp_fail(ctx, status, "requirement failed: " #cond, hipSuccess, __FILE__, __LINE__); \
+  } while (0)
+
+#define LAUNCH_CHECK(ctx) HIP_OK(ctx, hipGetLastError())
+
+/* grow-only workspace owned by the context */
+int sinterp_workspace(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
+
+/* dense building blocks shared by the Cholesky and LU drivers (gemm.hip) */
+/* C[m x n] -= A[m x k] * B^T   with B stored [n][k] (ldb)         -> b_is_kn = 0
+   C[m x n] -= A[m x k] * B     with B stored [k][n] (ldb)         -> b_is_kn = 1
+   lower_only: C is square on the diagonal, tiles strictly above it are skipped */
+int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, const double *A, size_t lda,
+                       const double *B, size_t ldb, int b_is_kn, double *C, size_t ldc, int lower_only);
+
+/* blocked triangular sweeps (chol.hip): the block being solved is read from b and
+   written to xout (b != xout), the remaining right-hand side is updated in b.
+   mode 0 Lower/NoTrans fwd, 1 Lower/Trans bwd, 2 Upper/NoTrans bwd */
+int sinterp_trsv(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, int mode,
+                 int unit);
+
+#endif

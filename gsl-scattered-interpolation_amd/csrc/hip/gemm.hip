@@ -1,0 +1,178 @@
+/*
+ * gemm.hip -- the Level-3 building block of the dense solves: C -= A * op(B) on
+ * v_mfma_f64_16x16x4_f64 (gfx950).  The reference factorizations are Level-2
+ * (linalg/cholesky.c:105-116 gaxpy via cblas/source_gemv_r.h:60-75;
+ * linalg/lu.c:105-119 rank-1 updates); the blocked drivers in chol.hip / lu.hip
+ * move all O(N^3) work here (the role gsl_blas_dsyrk / dgemm / dtrsm,
+ * blas/blas.c:1334,1649,2105, would play in a blocked GSL routine).
+ *
+ * Tiling (one workgroup = 256 threads = 4 waves, 2x2):
+ *   block tile 128 x 128, K step 16, double-buffered LDS, register-staged
+ *   prefetch of the next K step issued before the MFMAs of the current one;
+ *   each wave owns a 64 x 64 sub-tile = 4 x 4 MFMA fragments (16 accumulators
+ *   of 4 f64 -> 128 VGPRs), 64 MFMAs per K step.
+ * LDS images:
+ *   A (and B when stored [n][k]) as [row][16 + 2]: the fragment read
+ *   (row = lane&15, k = lane>>4) is a conflict-free ds_read_b64 because the
+ *   row pitch (18 doubles) is = 2 mod 4;
+ *   B stored [k][n] as [k][128 + 16]: consecutive lanes read consecutive n.
+ * MFMA operand maps (cdna_hip_programming.md section 3): A[i=lane&15][k=lane>>4],
+ *   B[k=lane>>4][j=lane&15], D[row=(lane>>4)+4*reg][col=lane&15].
+ */
+#include "common.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define GT_BM 128
+#define GT_BN 128
+#define GT_BK 16
+#define GT_LDA (GT_BK + 2)      /* 18 */
+#define GT_LDBN (GT_BN + 16)    /* 144 */
+#define GT_ASZ (GT_BM * GT_LDA) /* 2304 doubles */
+#define GT_BSZ 2304             /* max(128*18, 16*144) */
+
+struct GemmArgs {
+  size_t m, n, k;
+  const double *A; size_t lda;
+  const double *B; size_t ldb;
+  double *C; size_t ldc;
+  int lower_only;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ double2 ld2(const double *p, bool ok0, bool ok1, bool vec)
+{
+  if (vec && ok1) return *reinterpret_cast<const double2 *>(p);
+  double2 v;
+  v.x = ok0 ? p[0] : 0.0;
+  v.y = ok1 ? p[1] : 0.0;
+  return v;
+}
+
+template <int B_IS_KN>
+__global__ void __launch_bounds__(256, 2)
+gemm_minus_kernel(GemmArgs g)
+{
+  __shared__ __attribute__((aligned(16))) double sA[2][GT_ASZ];
+  __shared__ __attribute__((aligned(16))) double sB[2][GT_BSZ];
+
+  /* XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
+     each XCD a contiguous run of tiles (bijective for any grid size) */
+  const unsigned nwg = gridDim.x, bid = blockIdx.x;
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+  const unsigned tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  const int tm = (int)(tile / g.tiles_n), tn = (int)(tile % g.tiles_n);
+  if (g.lower_only && tn > tm) return;
+
+  const size_t row0 = (size_t)tm * GT_BM, col0 = (size_t)tn * GT_BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const bool vecA = ((g.lda & 1) == 0) && ((((uintptr_t)g.A) & 15) == 0);
+  const bool vecB = ((g.ldb & 1) == 0) && ((((uintptr_t)g.B) & 15) == 0);
+
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  double2 ra[4], rb[4];
+
+  auto fetch = [&](size_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + 256 * i;
+      { /* A: 128 rows x 8 chunks of 2 */
+        const int rr = c >> 3, kc = (c & 7) * 2;
+        const size_t grow = row0 + rr, gk = k0 + kc;
+        const bool okr = grow < g.m;
+        ra[i] = ld2(g.A + grow * g.lda + gk, okr && gk < g.k, okr && gk + 1 < g.k, vecA);
+      }
+      if (B_IS_KN) { /* B[k][n]: 16 rows x 64 chunks of 2 */
+        const int kk = c >> 6, nc = (c & 63) * 2;
+        const size_t gk = k0 + kk, gcol = col0 + nc;
+        const bool okk = gk < g.k;
+        rb[i] = ld2(g.B + gk * g.ldb + gcol, okk && gcol < g.n, okk && gcol + 1 < g.n, vecB);
+      } else { /* B[n][k]: 128 rows x 8 chunks of 2 */
+        const int rr = c >> 3, kc = (c & 7) * 2;
+        const size_t gn = col0 + rr, gk = k0 + kc;
+        const bool okn = gn < g.n;
+        rb[i] = ld2(g.B + gn * g.ldb + gk, okn && gk < g.k, okn && gk + 1 < g.k, vecB);
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + 256 * i;
+      { const int rr = c >> 3, kc = (c & 7) * 2;
+        *reinterpret_cast<double2 *>(&sA[buf][rr * GT_LDA + kc]) = ra[i]; }
+      if (B_IS_KN) { const int kk = c >> 6, nc = (c & 63) * 2;
+        *reinterpret_cast<double2 *>(&sB[buf][kk * GT_LDBN + nc]) = rb[i]; }
+      else { const int rr = c >> 3, kc = (c & 7) * 2;
+        *reinterpret_cast<double2 *>(&sB[buf][rr * GT_LDA + kc]) = rb[i]; }
+    }
+  };
+
+  const size_t nsteps = (g.k + GT_BK - 1) / GT_BK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  for (size_t s = 0; s < nsteps; s++) {
+    const int buf = (int)(s & 1);
+    if (s + 1 < nsteps) fetch((s + 1) * GT_BK);   /* in flight under the MFMAs */
+    const double *a_base = &sA[buf][(wr * 64 + fr) * GT_LDA + fq];
+    const double *b_base = B_IS_KN ? &sB[buf][fq * GT_LDBN + wc * 64 + fr] : &sB[buf][(wc * 64 + fr) * GT_LDA + fq];
+#pragma unroll
+    for (int kk = 0; kk < GT_BK / 4; kk++) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) af[i] = a_base[i * 16 * GT_LDA + kk * 4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) bf[j] = B_IS_KN ? b_base[kk * 4 * GT_LDBN + j * 16] : b_base[j * 16 * GT_LDA + kk * 4];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) stash(buf ^ 1);           /* other buffer: last read before the previous barrier */
+    __syncthreads();
+  }
+
+  /* epilogue: C -= acc.  D[row=(lane>>4)+4*reg][col=lane&15] */
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const size_t gcol = col0 + wc * 64 + j * 16 + fr;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const size_t grow = row0 + wr * 64 + i * 16 + fq + 4 * rg;
+        if (grow < g.m && gcol < g.n && (!g.lower_only || gcol <= grow)) {
+          double *p = g.C + grow * g.ldc + gcol;
+          *p = *p - acc[i][j][rg];
+        }
+      }
+    }
+  }
+}
+
+int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, const double *A, size_t lda,
+                       const double *B, size_t ldb, int b_is_kn, double *C, size_t ldc, int lower_only)
+{
+  if (m == 0 || n == 0 || k == 0) return ST_SUCCESS;
+  GemmArgs g;
+  g.m = m; g.n = n; g.k = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.lower_only = lower_only;
+  g.tiles_m = (int)((m + GT_BM - 1) / GT_BM);
+  g.tiles_n = (int)((n + GT_BN - 1) / GT_BN);
+  const unsigned grid = (unsigned)g.tiles_m * (unsigned)g.tiles_n;
+  if (b_is_kn) hipLaunchKernelGGL(gemm_minus_kernel<1>, dim3(grid), dim3(256), 0, ctx->stream, g);
+  else hipLaunchKernelGGL(gemm_minus_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, g);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}

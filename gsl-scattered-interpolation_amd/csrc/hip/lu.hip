@@ -1,0 +1,252 @@
+/*
+ * lu.hip -- general dense solve for kernels that are not SPD (thin-plate
+ * spline: zero diagonal, indefinite).
+ *
+ * Replaces gsl_linalg_LU_decomp (linalg/lu.c:59-124) and gsl_linalg_LU_svx
+ * (linalg/lu.c:166-201).  Same contract: P A = L U in place with partial
+ * pivoting, the pivot of a column is the FIRST row attaining max |a| (strict
+ * '>' scan, lu.c:82-93), multipliers stored below the diagonal, the permutation
+ * returned in gsl_permutation form (row i of PA is row perm[i] of A) with
+ * signum = (-1)^swaps; a zero pivot leaves its column untouched (lu.c:105).
+ *
+ * The reference is an unblocked kij sweep.  Here: recursive panel LU (Toledo):
+ *     lu(j0, w):  if w <= 8: pivoted base kernel on the tall panel
+ *                 else lu(j0, w/2); swap rows of the right half; U12 <- L11^-1 U12;
+ *                      A22 -= A21 U12 (gemm.hip, fp64 MFMA); lu(j0+w/2, w-w/2);
+ *                      swap rows of the left half
+ * The pivot search stays a per-column reduction (inherent to partial pivoting);
+ * everything else is Level-3.
+ */
+#include "common.h"
+#include <math.h>
+#include <stdlib.h>
+
+#define LB 8            /* base panel width */
+#define LU_THREADS 1024
+#define TB 16           /* triangular-solve base */
+
+/* ------------------------------------------------------------------------ */
+/* base: tall panel A[j0:n, j0:j0+w], one workgroup, rows strided over threads */
+__global__ void __launch_bounds__(LU_THREADS)
+lu_base_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int w, int *__restrict__ ipiv)
+{
+  __shared__ double s_val[LU_THREADS / 64];
+  __shared__ unsigned long long s_row[LU_THREADS / 64];
+  __shared__ double s_prow[LB];
+  __shared__ unsigned long long s_piv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int j = 0; j < w; j++) {
+    const size_t col = j0 + j;
+    /* ---- pivot search over rows col..n-1: max |a|, first row on ties ---- */
+    double best = -1.0;
+    unsigned long long brow = ~0ULL;
+    for (size_t i = col + tid; i < n; i += LU_THREADS) {
+      const double v = fabs(A[i * lda + col]);
+      if (v > best) { best = v; brow = i; }        /* ascending i per thread: keeps the first */
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(best, off);
+      const unsigned long long orow = __shfl_xor(brow, off);
+      if (ov > best || (ov == best && orow < brow)) { best = ov; brow = orow; }
+    }
+    if (lane == 0) { s_val[wave] = best; s_row[wave] = brow; }
+    __syncthreads();
+    if (tid == 0) {
+      double bv = s_val[0]; unsigned long long br = s_row[0];
+      for (int k = 1; k < LU_THREADS / 64; k++)
+        if (s_val[k] > bv || (s_val[k] == bv && s_row[k] < br)) { bv = s_val[k]; br = s_row[k]; }
+      /* NaN column or empty: keep the diagonal row */
+      if (br == ~0ULL) br = col;
+      s_piv = br;
+      ipiv[col] = (int)br;
+    }
+    __syncthreads();
+    const size_t piv = (size_t)s_piv;
+    /* ---- swap rows col <-> piv inside the panel, publish the pivot row ---- */
+    if (tid < w) {
+      const double a = A[col * lda + j0 + tid];
+      const double b = A[piv * lda + j0 + tid];
+      if (piv != col) { A[col * lda + j0 + tid] = b; A[piv * lda + j0 + tid] = a; }
+      s_prow[tid] = b;
+    }
+    __syncthreads();
+    const double ajj = s_prow[j];
+    if (ajj != 0.0) {                               /* lu.c:105 */
+      for (size_t i = col + 1 + tid; i < n; i += LU_THREADS) {
+        double *row = A + i * lda + j0;
+        const double l = row[j] / ajj;
+        row[j] = l;
+        for (int k = j + 1; k < w; k++) row[k] = row[k] - l * s_prow[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+/* apply the row interchanges k = k0..k1-1 (row k <-> ipiv[k]) to columns c0..c0+nc-1 */
+__global__ void __launch_bounds__(256)
+laswp_kernel(double *__restrict__ A, size_t lda, size_t c0, size_t nc, const int *__restrict__ ipiv, size_t k0, size_t k1)
+{
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nc) return;
+  double *col = A + c0 + c;
+  for (size_t k = k0; k < k1; k++) {
+    const size_t p = (size_t)ipiv[k];
+    if (p != k) {
+      const double a = col[k * lda], b = col[p * lda];
+      col[k * lda] = b; col[p * lda] = a;
+    }
+  }
+}
+
+/* B <- L^-1 B, L unit lower nb x nb (nb <= 32) at A[r0.., r0..], B = A[r0:r0+nb, c0:c0+nc];
+   one column of B per thread, kept in registers */
+__global__ void __launch_bounds__(256)
+trsm_unit_lower_base_kernel(double *__restrict__ A, size_t lda, size_t r0, int nb, size_t c0, size_t nc)
+{
+  __shared__ double sL[TB][TB + 1];
+  for (int e = threadIdx.x; e < TB * TB; e += 256) {
+    const int r = e / TB, k = e % TB;
+    sL[r][k] = (r < nb && k < r) ? A[(r0 + r) * lda + r0 + k] : 0.0;
+  }
+  __syncthreads();
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nc) return;
+  double *col = A + r0 * lda + c0 + c;
+  double x[TB];
+#pragma unroll
+  for (int r = 0; r < TB; r++) x[r] = r < nb ? col[(size_t)r * lda] : 0.0;
+#pragma unroll
+  for (int r = 1; r < TB; r++) {
+    double v = x[r];
+#pragma unroll
+    for (int k = 0; k < r; k++) v -= sL[r][k] * x[k];
+    x[r] = v;
+  }
+#pragma unroll
+  for (int r = 0; r < TB; r++) if (r < nb) col[(size_t)r * lda] = x[r];
+}
+
+static int trsm_unit_lower(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t r0, size_t nb, size_t c0, size_t nc)
+{
+  if (nb == 0 || nc == 0) return ST_SUCCESS;
+  if (nb <= TB) {
+    hipLaunchKernelGGL(trsm_unit_lower_base_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, A, lda,
+                       r0, (int)nb, c0, nc);
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
+  size_t n1 = ((nb / 2 + TB - 1) / TB) * TB;
+  if (n1 >= nb) n1 = nb - TB;
+  int st = trsm_unit_lower(ctx, A, lda, r0, n1, c0, nc);
+  if (st) return st;
+  /* B2 -= L21 * X1 :  L21 = A[r0+n1 : r0+nb, r0 : r0+n1],  X1 = A[r0 : r0+n1, c0 : c0+nc] */
+  st = sinterp_gemm_minus(ctx, nb - n1, nc, n1, A + (r0 + n1) * lda + r0, lda, A + r0 * lda + c0, lda, 1,
+                          A + (r0 + n1) * lda + c0, lda, 0);
+  if (st) return st;
+  return trsm_unit_lower(ctx, A, lda, r0 + n1, nb - n1, c0, nc);
+}
+
+static int lu_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, size_t j0, size_t w, int *d_ipiv)
+{
+  if (w <= LB) {
+    hipLaunchKernelGGL(lu_base_kernel, dim3(1), dim3(LU_THREADS), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
+  size_t w1 = ((w / 2 + LB - 1) / LB) * LB;
+  if (w1 >= w) w1 = w - LB;
+  const size_t w2 = w - w1, c1 = j0 + w1;
+  int st = lu_panel(ctx, A, lda, n, j0, w1, d_ipiv);
+  if (st) return st;
+  hipLaunchKernelGGL(laswp_kernel, dim3((unsigned)((w2 + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, c1, w2, d_ipiv, j0, c1);
+  LAUNCH_CHECK(ctx);
+  st = trsm_unit_lower(ctx, A, lda, j0, w1, c1, w2);             /* U12 = L11^-1 A12 */
+  if (st) return st;
+  st = sinterp_gemm_minus(ctx, n - c1, w2, w1, A + c1 * lda + j0, lda, A + j0 * lda + c1, lda, 1,
+                          A + c1 * lda + c1, lda, 0);           /* A22 -= A21 U12 */
+  if (st) return st;
+  st = lu_panel(ctx, A, lda, n, c1, w2, d_ipiv);
+  if (st) return st;
+  hipLaunchKernelGGL(laswp_kernel, dim3((unsigned)((w1 + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, j0, w1, d_ipiv, c1,
+                     c1 + w2 < n ? c1 + w2 : n);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *d_perm,
+                                         int *h_signum)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, lda >= n && n < 2147483647ULL, ST_EINVAL);
+  REQUIRE(ctx, n == 0 || (d_a && d_perm), ST_EFAULT);
+  if (h_signum) *h_signum = 1;
+  if (n == 0) return ST_SUCCESS;
+  int st = lu_panel(ctx, d_a, lda, n, 0, n, d_perm);              /* d_perm holds LAPACK-style ipiv for now */
+  if (st) return st;
+  /* ipiv -> gsl_permutation content + signum (lu.c:95-101) */
+  int *h_ipiv = (int *)malloc(n * sizeof(int));
+  int *h_perm = (int *)malloc(n * sizeof(int));
+  if (!h_ipiv || !h_perm) { free(h_ipiv); free(h_perm); return sinterp_fail(ctx, ST_ENOMEM, "lu_decomp: host buffers", hipSuccess, __FILE__, __LINE__); }
+  hipError_t e = hipMemcpyAsync(h_ipiv, d_perm, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  int sign = 1;
+  if (e == hipSuccess) {
+    for (size_t i = 0; i < n; i++) h_perm[i] = (int)i;
+    for (size_t k = 0; k < n; k++) {
+      const int p = h_ipiv[k];
+      if (p != (int)k && p >= 0 && (size_t)p < n) { int t = h_perm[k]; h_perm[k] = h_perm[p]; h_perm[p] = t; sign = -sign; }
+    }
+    e = hipMemcpyAsync(d_perm, h_perm, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  free(h_ipiv); free(h_perm);
+  if (e != hipSuccess) return sinterp_fail(ctx, ST_EFAILED, "lu_decomp: pivot transfer", e, __FILE__, __LINE__);
+  if (h_signum) *h_signum = sign;
+  return ST_SUCCESS;
+}
+
+__global__ void permute_gather_kernel(const double *__restrict__ src, const int *__restrict__ perm, double *__restrict__ dst, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[perm[i]];                 /* permutation/permute_source.c:140 */
+}
+
+__global__ void lu_singular_kernel(const double *__restrict__ lu, size_t lda, size_t n, int *__restrict__ flag)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && lu[i * lda + i] == 0.0) atomicExch(flag, 1);   /* linear_simplex_util.h:14-26 / lu.c:181 */
+}
+
+extern "C" int gsl_sinterp_hip_lu_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_lu, size_t lda,
+                                      const int *d_perm, double *d_x)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, lda >= n, ST_EINVAL);
+  REQUIRE(ctx, n == 0 || (d_lu && d_perm && d_x), ST_EFAULT);
+  if (n == 0) return ST_SUCCESS;
+  int *d_flag = (int *)ctx->d_scratch + 16;
+  HIP_OK(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(lu_singular_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_lu, lda, n, d_flag);
+  LAUNCH_CHECK(ctx);
+  int flag = 0;
+  HIP_OK(ctx, hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  if (flag) return sinterp_fail(ctx, ST_EDOM, "lu_svx: matrix is singular", hipSuccess, __FILE__, __LINE__);
+
+  void *d_tmp = NULL;
+  int st = sinterp_workspace(ctx, n * sizeof(double), &d_tmp);
+  if (st) return st;
+  double *tmp = (double *)d_tmp;
+  hipLaunchKernelGGL(permute_gather_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_x, d_perm, tmp, n);   /* tmp = P b */
+  LAUNCH_CHECK(ctx);
+  st = sinterp_trsv(ctx, n, d_lu, lda, tmp, d_x, 0, 1);     /* L c = P b, unit lower: solved blocks -> d_x   */
+  if (st) return st;
+  /* back substitution reads d_x as right-hand side, writes solved blocks to tmp */
+  st = sinterp_trsv(ctx, n, d_lu, lda, d_x, tmp, 2, 0);     /* U x = c */
+  if (st) return st;
+  HIP_OK(ctx, hipMemcpyAsync(d_x, tmp, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return ST_SUCCESS;
+}

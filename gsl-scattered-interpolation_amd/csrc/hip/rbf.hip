@@ -1,0 +1,263 @@
+/*
+ * rbf.hip -- radial-kernel matrix fill and the N x M evaluation sweep.
+ *
+ * The reference holds no RBF code (README:18-26); SURVEY.md 3.3/3.4 fixes what
+ * is computed:  Phi_ij = phi(|x_i - x_j|)  and  s(y_k) = sum_j w_j phi(|y_k - x_j|)
+ * with j ascending (one accumulator per target, so the summation order is the
+ * CPU oracle's; only exp/log rounding and FMA contraction differ).
+ *
+ *   fill : HBM-write bound (8 B per entry), 16-byte stores, centres via cache.
+ *   eval : fp64-VALU bound (~N x 16 ops per target); centre tiles + weights
+ *          staged through LDS and broadcast to the wave, TPT targets per lane
+ *          for ILP; exp / log evaluated with 256-entry LDS tables and short
+ *          polynomials (<= 2 ulp, far inside the 1e-10 parity tolerance).
+ */
+#include "common.h"
+#include <math.h>
+
+#define TBL_BITS 8
+#define TBL_N (1 << TBL_BITS)
+
+/* tables live in global memory (built once per context on first use) and are
+   copied into LDS by each workgroup */
+struct RbfTables {
+  double exp2_frac[TBL_N];      /* 2^(i/256)                        */
+  double log_inv[TBL_N];        /* 1/c_i, c_i = 1 + (i+0.5)/256     */
+  double log_val[TBL_N];        /* ln c_i                           */
+};
+
+__device__ RbfTables g_rbf_tables;
+static bool g_tables_ready[64] = {false};
+
+static int ensure_tables(gsl_sinterp_hip_ctx *ctx)
+{
+  if (ctx->device < 64 && g_tables_ready[ctx->device]) return ST_SUCCESS;
+  static RbfTables h;
+  for (int i = 0; i < TBL_N; i++) {
+    h.exp2_frac[i] = exp2((double)i / TBL_N);
+    double c = 1.0 + ((double)i + 0.5) / TBL_N;
+    h.log_inv[i] = 1.0 / c;
+    h.log_val[i] = log(c);
+  }
+  HIP_OK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_rbf_tables), &h, sizeof h, 0, hipMemcpyHostToDevice));
+  if (ctx->device < 64) g_tables_ready[ctx->device] = true;
+  return ST_SUCCESS;
+}
+
+/* 2^t for t <= 0 (and moderate t > 0): t*256 = k + f, |f| <= 1/2;
+   2^t = 2^(k>>8) * T[k&255] * exp(f ln2/256), degree-4 Taylor (|arg| <= 1.36e-3,
+   truncation 3.8e-17) */
+__device__ __forceinline__ double exp2_tbl(double t, const double *__restrict__ tbl)
+{
+  t = fmax(t, -1100.0);
+  const double ts = t * (double)TBL_N;
+  const double kf = rint(ts);
+  const double f = ts - kf;                       /* exact */
+  const int k = (int)kf;
+  const double a = f * (0.693147180559945309417232 / TBL_N);
+  double p = fma(a, 1.0 / 24.0, 1.0 / 6.0);
+  p = fma(p, a, 0.5);
+  p = fma(p, a, 1.0);
+  p = fma(p, a, 1.0);
+  return ldexp(tbl[k & (TBL_N - 1)] * p, k >> TBL_BITS);
+}
+
+/* ln(v), v > 0 finite normal: v = 2^e m, m in [1,2); u = m/c - 1, |u| <= 2^-9 */
+__device__ __forceinline__ double log_tbl(double v, const double *__restrict__ inv, const double *__restrict__ val)
+{
+  int e;
+  double m = frexp(v, &e);                         /* m in [0.5,1) */
+  m *= 2.0; e -= 1;
+  const int idx = (int)((m - 1.0) * (double)TBL_N);
+  const double u = fma(m, inv[idx], -1.0);
+  /* log1p(u) = u - u^2/2 + u^3/3 - u^4/4 + u^5/5 - u^6/6, |u|^7/7 < 1.5e-20 */
+  double p = fma(u, -1.0 / 6.0, 0.2);
+  p = fma(p, u, -0.25);
+  p = fma(p, u, 1.0 / 3.0);
+  p = fma(p, u, -0.5);
+  p = fma(p, u, 1.0);
+  return fma((double)e, 0.693147180559945309417232, fma(p, u, val[idx]));
+}
+
+template <int KIND>
+__device__ __forceinline__ double phi_r2(double r2, double coef, const double *__restrict__ t0,
+                                         const double *__restrict__ t1, const double *__restrict__ t2)
+{
+  if (KIND == GSL_SINTERP_RBF_GAUSSIAN) {
+    return exp2_tbl(r2 * coef, t0);                /* coef = -eps^2 log2(e) */
+  } else {
+    double l = log_tbl(fmax(r2, 1e-300), t1, t2);
+    double v = (0.5 * r2) * l;                     /* r^2 ln r */
+    return r2 > 0.0 ? v : 0.0;
+  }
+}
+
+__device__ __forceinline__ void load_tables(double *s_t0, double *s_t1, double *s_t2, int kind)
+{
+  for (int i = threadIdx.x; i < TBL_N; i += blockDim.x) {
+    if (kind == GSL_SINTERP_RBF_GAUSSIAN) s_t0[i] = g_rbf_tables.exp2_frac[i];
+    else { s_t1[i] = g_rbf_tables.log_inv[i]; s_t2[i] = g_rbf_tables.log_val[i]; }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* fill: block = 256 threads -> 16 rows x 128 cols, 2 columns (16 B) per lane */
+template <int KIND, int DIM>
+__global__ void __launch_bounds__(256)
+rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, double *__restrict__ phi, size_t lda)
+{
+  __shared__ double s_t0[TBL_N], s_t1[TBL_N], s_t2[TBL_N];
+  load_tables(s_t0, s_t1, s_t2, KIND);
+  __syncthreads();
+  const size_t j0 = ((size_t)blockIdx.x * 64 + (threadIdx.x & 63)) * 2;
+  const size_t ibase = (size_t)blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+  if (j0 >= n) return;
+  const bool two = j0 + 1 < n;
+  double xa[DIM], xb[DIM];
+#pragma unroll
+  for (int c = 0; c < DIM; c++) { xa[c] = x[j0 * xtda + c]; xb[c] = two ? x[(j0 + 1) * xtda + c] : 0.0; }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const size_t i = ibase + r;
+    if (i >= n) break;
+    double ra = 0.0, rb = 0.0;
+#pragma unroll
+    for (int c = 0; c < DIM; c++) {
+      const double xi = x[i * xtda + c];
+      const double da = xi - xa[c], db = xi - xb[c];
+      ra = fma(da, da, ra); rb = fma(db, db, rb);
+    }
+    const double va = phi_r2<KIND>(ra, coef, s_t0, s_t1, s_t2);
+    const double vb = phi_r2<KIND>(rb, coef, s_t0, s_t1, s_t2);
+    double *dst = phi + i * lda + j0;
+    if (two && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<double2 *>(dst) = make_double2(va, vb);
+    else { dst[0] = va; if (two) dst[1] = vb; }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* eval sweep: TPT targets per lane, centre tile of TJ entries in LDS          */
+#define EV_THREADS 256
+#define EV_TJ 512
+
+template <int KIND, int DIM, int TPT>
+__global__ void __launch_bounds__(EV_THREADS)
+rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, const double *__restrict__ w,
+                const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s)
+{
+  __shared__ double s_t0[TBL_N], s_t1[TBL_N], s_t2[TBL_N];
+  __shared__ double s_c[EV_TJ * (DIM + 1)];       /* per centre: x[0..DIM-1], w */
+  load_tables(s_t0, s_t1, s_t2, KIND);
+
+  const size_t k0 = ((size_t)blockIdx.x * EV_THREADS) * TPT + threadIdx.x;
+  double yy[TPT][DIM], acc[TPT];
+#pragma unroll
+  for (int t = 0; t < TPT; t++) {
+    const size_t k = k0 + (size_t)t * EV_THREADS;
+    acc[t] = 0.0;
+#pragma unroll
+    for (int c = 0; c < DIM; c++) yy[t][c] = k < m ? y[k * ytda + c] : 0.0;
+  }
+
+  for (size_t jt = 0; jt < n; jt += EV_TJ) {
+    const int cnt = (int)((n - jt) < (size_t)EV_TJ ? (n - jt) : (size_t)EV_TJ);
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt; e += EV_THREADS) {
+#pragma unroll
+      for (int c = 0; c < DIM; c++) s_c[e * (DIM + 1) + c] = x[(jt + e) * xtda + c];
+      s_c[e * (DIM + 1) + DIM] = w[jt + e];
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int e = 0; e < cnt; e++) {
+      double xc[DIM];
+#pragma unroll
+      for (int c = 0; c < DIM; c++) xc[c] = s_c[e * (DIM + 1) + c];
+      const double wj = s_c[e * (DIM + 1) + DIM];
+#pragma unroll
+      for (int t = 0; t < TPT; t++) {
+        double r2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < DIM; c++) { const double d = yy[t][c] - xc[c]; r2 = fma(d, d, r2); }
+        acc[t] = fma(wj, phi_r2<KIND>(r2, coef, s_t0, s_t1, s_t2), acc[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TPT; t++) {
+    const size_t k = k0 + (size_t)t * EV_THREADS;
+    if (k < m) s[k] = acc[t];
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+static double kernel_coef(int kind, double eps)
+{
+  return kind == GSL_SINTERP_RBF_GAUSSIAN ? -(eps * eps) * 1.44269504088896340735992 : 0.0;
+}
+
+template <int KIND>
+static int launch_fill(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x, size_t n, int dim, size_t xtda,
+                       double *d_phi, size_t lda)
+{
+  dim3 grid((unsigned)((n + 127) / 128), (unsigned)((n + 15) / 16));
+  switch (dim) {
+    case 1: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 1>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda); break;
+    case 2: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 2>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda); break;
+    default: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 3>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda); break;
+  }
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_rbf_fill(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
+                                        int dim, size_t xtda, double *d_phi, size_t lda)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && lda >= n, ST_EINVAL);
+  REQUIRE(ctx, kind == GSL_SINTERP_RBF_GAUSSIAN || kind == GSL_SINTERP_RBF_TPS, ST_EINVAL);
+  REQUIRE(ctx, n == 0 || (d_x && d_phi), ST_EFAULT);
+  REQUIRE(ctx, (n + 15) / 16 <= 65535, ST_EINVAL);
+  if (n == 0) return ST_SUCCESS;
+  int st = ensure_tables(ctx);
+  if (st) return st;
+  const double coef = kernel_coef(kind, eps);
+  return kind == GSL_SINTERP_RBF_GAUSSIAN ? launch_fill<GSL_SINTERP_RBF_GAUSSIAN>(ctx, coef, d_x, n, dim, xtda, d_phi, lda)
+                                          : launch_fill<GSL_SINTERP_RBF_TPS>(ctx, coef, d_x, n, dim, xtda, d_phi, lda);
+}
+
+template <int KIND, int TPT>
+static int launch_eval(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x, size_t n, int dim, size_t xtda,
+                       const double *d_w, const double *d_y, size_t m, size_t ytda, double *d_s)
+{
+  const size_t per_block = (size_t)EV_THREADS * TPT;
+  dim3 grid((unsigned)((m + per_block - 1) / per_block));
+  switch (dim) {
+    case 1: hipLaunchKernelGGL((rbf_eval_kernel<KIND, 1, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, d_x, n, xtda, d_w, d_y, m, ytda, d_s); break;
+    case 2: hipLaunchKernelGGL((rbf_eval_kernel<KIND, 2, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, d_x, n, xtda, d_w, d_y, m, ytda, d_s); break;
+    default: hipLaunchKernelGGL((rbf_eval_kernel<KIND, 3, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, d_x, n, xtda, d_w, d_y, m, ytda, d_s); break;
+  }
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
+                                        int dim, size_t xtda, const double *d_w, const double *d_y, size_t m,
+                                        size_t ytda, double *d_s)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && ytda >= (size_t)dim, ST_EINVAL);
+  REQUIRE(ctx, kind == GSL_SINTERP_RBF_GAUSSIAN || kind == GSL_SINTERP_RBF_TPS, ST_EINVAL);
+  REQUIRE(ctx, m == 0 || (d_y && d_s && (n == 0 || (d_x && d_w))), ST_EFAULT);
+  if (m == 0) return ST_SUCCESS;
+  int st = ensure_tables(ctx);
+  if (st) return st;
+  const double coef = kernel_coef(kind, eps);
+  /* few targets: 1 per lane keeps more CUs busy; many: 2 per lane for ILP */
+  const bool small = m < (size_t)EV_THREADS * 2 * 512;
+  if (kind == GSL_SINTERP_RBF_GAUSSIAN)
+    return small ? launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s)
+                 : launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s);
+  return small ? launch_eval<GSL_SINTERP_RBF_TPS, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s)
+               : launch_eval<GSL_SINTERP_RBF_TPS, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s);
+}

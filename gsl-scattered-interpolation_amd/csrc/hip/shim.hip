@@ -1,0 +1,162 @@
+/*
+ * shim.hip -- context, memory, timing and synthetic-cloud entry points of the
+ * C-ABI (include/gsl_sinterp_hip.h).  The reference has no device boundary at
+ * all; this file is that boundary.
+ */
+#include "common.h"
+
+extern "C" int gsl_sinterp_hip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int gsl_sinterp_hip_ctx_create(gsl_sinterp_hip_ctx **out, int device, void *stream)
+{
+  if (!out) return ST_EFAULT;
+  *out = NULL;
+  int n = gsl_sinterp_hip_device_count();
+  if (n <= 0 || device < 0 || device >= n) return ST_EFAILED;
+  gsl_sinterp_hip_ctx *ctx = new (std::nothrow) gsl_sinterp_hip_ctx();
+  if (!ctx) return ST_ENOMEM;
+  memset(ctx, 0, sizeof *ctx);
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return ST_EFAILED; }
+  if (stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = 0; }
+  else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ST_EFAILED; }
+    ctx->owns_stream = 1;
+  }
+  ctx->scratch_bytes = 4096;
+  if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      hipMalloc(&ctx->d_scratch, ctx->scratch_bytes) != hipSuccess) {
+    gsl_sinterp_hip_ctx_destroy(ctx);
+    return ST_EFAILED;
+  }
+  *out = ctx;
+  return ST_SUCCESS;
+}
+
+extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->d_work) (void)hipFree(ctx->d_work);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char *gsl_sinterp_hip_last_error(const gsl_sinterp_hip_ctx *ctx)
+{
+  return ctx ? ctx->err : "no HIP context (no usable gfx950 device?)";
+}
+
+extern "C" int gsl_sinterp_hip_sync(gsl_sinterp_hip_ctx *ctx)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_malloc(gsl_sinterp_hip_ctx *ctx, void **d_ptr, size_t bytes)
+{
+  REQUIRE(ctx, ctx != NULL && d_ptr != NULL, ST_EFAULT);
+  *d_ptr = NULL;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  HIP_OK(ctx, hipMalloc(d_ptr, bytes ? bytes : 8));
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_free(gsl_sinterp_hip_ctx *ctx, void *d_ptr)
+{
+  if (!d_ptr) return ST_SUCCESS;
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipFree(d_ptr));
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_h2d(gsl_sinterp_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  if (!bytes) return ST_SUCCESS;
+  HIP_OK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   /* pageable source: make reuse of h_src safe */
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_d2h(gsl_sinterp_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  if (!bytes) return ST_SUCCESS;
+  HIP_OK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_timer_start(gsl_sinterp_hip_ctx *ctx)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_timer_stop(gsl_sinterp_hip_ctx *ctx, float *h_ms)
+{
+  REQUIRE(ctx, ctx != NULL && h_ms != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_OK(ctx, hipEventSynchronize(ctx->ev1));
+  HIP_OK(ctx, hipEventElapsedTime(h_ms, ctx->ev0, ctx->ev1));
+  return ST_SUCCESS;
+}
+
+int sinterp_workspace(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out)
+{
+  if (bytes > ctx->work_bytes) {
+    if (ctx->d_work) {
+      HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_OK(ctx, hipFree(ctx->d_work));
+      ctx->d_work = NULL; ctx->work_bytes = 0;
+    }
+    HIP_OK(ctx, hipMalloc(&ctx->d_work, bytes));
+    ctx->work_bytes = bytes;
+  }
+  *out = ctx->d_work;
+  return ST_SUCCESS;
+}
+
+/* u(k) = (splitmix64(seed ^ k) >> 11) * 2^-53, out[i] = offset + span * u(first + i)
+   (same generator as oracle/oracle_synth.c so CPU and GPU see
+   identical clouds without a transfer) */
+__global__ void synth_unit_kernel(uint64_t seed, uint64_t first, double offset, double span,
+                                  double *__restrict__ out, size_t count)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    uint64_t z = (seed ^ (first + i)) + 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    double u = (double)(z >> 11) * 0x1.0p-53;
+    out[i] = offset + span * u;
+  }
+}
+
+extern "C" int gsl_sinterp_hip_synth_unit(gsl_sinterp_hip_ctx *ctx, uint64_t seed, uint64_t first,
+                                          double offset, double span, double *d_out, size_t count)
+{
+  REQUIRE(ctx, ctx != NULL && d_out != NULL, ST_EFAULT);
+  if (!count) return ST_SUCCESS;
+  size_t blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(synth_unit_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, seed, first, offset, span,
+                     d_out, count);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}

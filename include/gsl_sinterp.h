@@ -1,0 +1,192 @@
+/*
+ * gsl_sinterp.h -- host-side C API of the MI355X-native scattered-data
+ * interpolation library (libgsl_sinterp.so).
+ *
+ * Part 1 keeps the reference's existing scattered-interpolation symbols
+ * (interpolation/linear_simplex.h:105-179, interpolation/edge_flip.h:42-47)
+ * with their signatures, flags, `simplex_tree` field order and accessor macros,
+ * so a program written against the reference recompiles against this header.
+ * They run on the host, exactly like the reference: the Delaunay history DAG is
+ * built once on the CPU (2-D).
+ *
+ * Part 2 is the batched, GPU-only entry the reference lacks
+ * (simplex_tree_device_*): the DAG is mirrored into HBM and M targets are
+ * located + interpolated by one kernel.
+ *
+ * Part 3 is the gsl_sinterp facade shaped like gsl_interp
+ * (interpolation/gsl_interp.h:49-71, interpolation/interp.c:30-138):
+ * alloc(type, dim, n) / init / eval_e / eval / eval_many / free with three
+ * types: Gaussian RBF, thin-plate-spline RBF, linear simplex (barycentric).
+ *
+ * There is no CPU fallback for parts 2 and 3: without a usable gfx950 device
+ * they fail with GSL_EFAILED through the GSL error handler.
+ */
+#ifndef GSL_SINTERP_H
+#define GSL_SINTERP_H
+
+#include "gsl_sinterp_compat.h"
+#include "gsl_sinterp_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================== */
+/* Part 1: reference simplex_tree API (host)                                 */
+/* ======================================================================== */
+typedef int simplex_index;
+
+typedef enum { leaf_type = 0, sub_dplus1_type, sub_d_type, sub_2_type } node_type;
+
+typedef struct simplex_tree_node_struct {
+  int points;          /* offset of this node's vertex ids in pidx[]  */
+  simplex_index links; /* offset of this node's links in links[]      */
+  node_type type : 2;
+} simplex_tree_node;
+
+typedef struct {
+  gsl_matrix *simplex_matrix;
+  gsl_permutation *perm;
+  gsl_vector *coords;
+  simplex_index current_simplex;
+} simplex_tree_accel;
+
+typedef struct simplex_tree_struct {
+  int n_simplexes, max_simplexes;
+  simplex_tree_node *simplexes;
+  int n_pidx, max_pidx;
+  int *pidx;
+  int n_links, max_links;
+  simplex_index *links;
+  gsl_matrix *seed_points;
+  int n_points;
+  int max_points;
+  int dim;
+  gsl_vector *shift;
+  gsl_vector *scale;
+  gsl_vector *min;
+  gsl_vector *max;
+  gsl_permutation *shuffle;
+  simplex_tree_accel *accel;
+  simplex_index *new_simplexes;
+  simplex_index *old_neighbors1;
+  simplex_index *old_neighbors2;
+  int *left_out;
+  int *tmp_points1;
+  gsl_vector *tmp_vec1, *tmp_vec2;
+  gsl_matrix *tmp_mat;
+} simplex_tree;
+
+/* accessor macros with the reference's names; they expect a variable `tree` */
+#define SIMP(I) (&(tree->simplexes[(I)]))
+#define LINK(NODE, I) (tree->links[(I) + SIMP(NODE)->links])
+#define SLINK(NODE, I) (SIMP(LINK(NODE, I)))
+#define POINT(NODE, I) (tree->pidx[(I) + SIMP(NODE)->points])
+#define LEAF(NODE) (leaf_type == SIMP(NODE)->type)
+
+#define SIMPLEX_TREE_DEFAULT 0
+#define SIMPLEX_TREE_NOSTANDARDIZE (1 << 0)
+#define SIMPLEX_TREE_ISOSCALE (1 << 1)
+
+simplex_index simplex_tree_node_alloc(simplex_tree *tree);
+simplex_tree *simplex_tree_alloc(int dim, int n_points);
+int simplex_tree_init(simplex_tree *tree, gsl_matrix *data, gsl_vector *min, gsl_vector *max,
+                      int init_flags, gsl_rng *rng);
+void simplex_tree_free(simplex_tree *tree);
+simplex_tree_accel *simplex_tree_accel_alloc(int dim);
+void simplex_tree_accel_free(simplex_tree_accel *accel);
+int point_in_simplex(simplex_tree *tree, simplex_index node, int point);
+simplex_index find_leaf(simplex_tree *tree, gsl_matrix *data, gsl_vector *point,
+                        simplex_tree_accel *accel);
+simplex_index _find_leaf(simplex_tree *tree, simplex_index node, gsl_matrix *data,
+                         gsl_vector *point, simplex_tree_accel *accel);
+int insert_point(simplex_tree *tree, simplex_index leaf, gsl_matrix *data, gsl_vector *point,
+                 simplex_tree_accel *accel);
+int in_hypersphere(simplex_tree *tree, simplex_index node, gsl_matrix *data, int idx,
+                   simplex_tree_accel *accel);
+int in_hypersphere_points(simplex_tree *tree, int *points, gsl_matrix *data, int idx,
+                          simplex_tree_accel *accel);
+int calculate_hypersphere(simplex_tree *tree, simplex_index node, gsl_matrix *data,
+                          gsl_vector *x0, double *r2, simplex_tree_accel *accel);
+int calculate_hypersphere_points(simplex_tree *tree, int *points, gsl_matrix *data,
+                                 gsl_vector *x0, double *r2, simplex_tree_accel *accel);
+int calculate_bary_coords(simplex_tree *tree, simplex_index node, gsl_matrix *data,
+                          gsl_vector *point, simplex_tree_accel *accel);
+int contains_point(simplex_tree *tree, simplex_index node, gsl_matrix *data, gsl_vector *point,
+                   simplex_tree_accel *accel);
+double interp_point(simplex_tree *tree, simplex_index leaf, gsl_matrix *data,
+                    gsl_vector *response, gsl_vector *point, simplex_tree_accel *accel);
+int delaunay(simplex_tree *tree, simplex_index leaf, gsl_matrix *data, int face,
+             simplex_tree_accel *accel);
+
+/* ======================================================================== */
+/* Part 2: batched GPU evaluation over a built tree                          */
+/* ======================================================================== */
+typedef struct simplex_tree_device simplex_tree_device;
+
+/* Mirror `tree` (built over `data`) into the HBM of `device` (ordinal). */
+simplex_tree_device *simplex_tree_device_alloc(simplex_tree *tree, gsl_matrix *data, int device);
+void simplex_tree_device_free(simplex_tree_device *dev);
+/* Bind the response column used by the following eval calls. */
+int simplex_tree_device_set_response(simplex_tree_device *dev, const gsl_vector *response);
+/* find_leaf + interp_point for every row of `targets` (M x 2, tda honoured).
+   `leaf` may be NULL.  Rows outside the cage give leaf -1 / value NaN and the
+   call returns GSL_EDOM (no abort). */
+int simplex_tree_device_eval_many(simplex_tree_device *dev, const gsl_matrix *targets,
+                                  gsl_vector *values, simplex_index *leaf);
+/* Same, with targets / outputs already resident in HBM. */
+int simplex_tree_device_eval_resident(simplex_tree_device *dev, const double *d_targets, size_t m,
+                                      size_t ttda, double *d_values, simplex_index *d_leaf);
+gsl_sinterp_hip_ctx *simplex_tree_device_ctx(simplex_tree_device *dev);
+
+/* ======================================================================== */
+/* Part 3: gsl_sinterp facade                                                */
+/* ======================================================================== */
+typedef struct gsl_sinterp_struct gsl_sinterp;
+
+typedef struct {
+  const char *name;
+  unsigned int min_size;
+  void *(*alloc)(size_t dim, size_t size);
+  int (*init)(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *f);
+  int (*eval_many)(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vector *s, int *leaf);
+  int (*eval_resident)(const gsl_sinterp *interp, const double *d_y, size_t m, size_t ytda,
+                       double *d_s, int *d_leaf);
+  void (*free)(void *state);
+} gsl_sinterp_type;
+
+struct gsl_sinterp_struct {
+  const gsl_sinterp_type *type;
+  size_t dim;
+  size_t size;
+  int device;        /* GPU ordinal; default 0 or $GSL_SINTERP_DEVICE */
+  double shape;      /* Gaussian shape parameter eps; <= 0 -> 2 * size^(1/dim) */
+  int init_flags;    /* SIMPLEX_TREE_* flags (linear simplex type)            */
+  gsl_rng *rng;      /* insertion-order rng (linear simplex type), may be NULL */
+  void *state;
+};
+
+extern const gsl_sinterp_type *gsl_sinterp_rbf_gaussian;
+extern const gsl_sinterp_type *gsl_sinterp_rbf_tps;
+extern const gsl_sinterp_type *gsl_sinterp_linear_simplex;
+
+gsl_sinterp *gsl_sinterp_alloc(const gsl_sinterp_type *T, size_t dim, size_t size);
+int gsl_sinterp_set_device(gsl_sinterp *interp, int device);
+int gsl_sinterp_set_shape(gsl_sinterp *interp, double eps);
+int gsl_sinterp_set_tree_options(gsl_sinterp *interp, int init_flags, gsl_rng *rng);
+int gsl_sinterp_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *f);
+const char *gsl_sinterp_name(const gsl_sinterp *interp);
+unsigned int gsl_sinterp_min_size(const gsl_sinterp *interp);
+int gsl_sinterp_eval_e(const gsl_sinterp *interp, const gsl_vector *y, double *s);
+double gsl_sinterp_eval(const gsl_sinterp *interp, const gsl_vector *y);
+int gsl_sinterp_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vector *s, int *leaf);
+int gsl_sinterp_eval_resident(const gsl_sinterp *interp, const double *d_y, size_t m, size_t ytda,
+                              double *d_s, int *d_leaf);
+/* RBF types: copy the solved weights (length size) to the host. */
+int gsl_sinterp_get_weights(const gsl_sinterp *interp, gsl_vector *w);
+void gsl_sinterp_free(gsl_sinterp *interp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,107 @@
+/*
+ * gsl_sinterp_hip.h -- C-ABI of the MI355X (gfx950) kernels behind the
+ * scattered-interpolation hot path.  Plain pointers and sizes only; every
+ * `d_*` argument is a DEVICE pointer (hipMalloc / torch data_ptr), every
+ * `h_*` argument a host pointer.  All entry points return a GSL status code
+ * (include/gsl_sinterp_compat.h) and never abort; the text of the last failure
+ * is kept per context (gsl_sinterp_hip_last_error).
+ *
+ * Work is enqueued on the context's stream and is asynchronous unless the
+ * entry point has a host-side output (`info`, `signum`), in which case it
+ * synchronises the stream before returning.
+ *
+ * Reference routines each entry point replaces (paths under the reference
+ * tree, smithzvk/gsl-scattered-interpolation):
+ *   tree_pack + bary_eval   interpolation/linear_simplex.c:331-402 (find_leaf/_find_leaf),
+ *                           :607-651 (calculate_bary_coords), :653-676 (contains_point),
+ *                           :678-711 (interp_point); linalg/lu.c:59-201 at d=2
+ *   rbf_fill                (no reference code; README:18-26) Phi_ij = phi(|x_i-x_j|)
+ *   cholesky_decomp1        linalg/cholesky.c:88-131  (gsl_linalg_cholesky_decomp1)
+ *   cholesky_svx            linalg/cholesky.c:163-185 (gsl_linalg_cholesky_svx)
+ *   lu_decomp / lu_svx      linalg/lu.c:59-124, :166-201 (gsl_linalg_LU_decomp / _svx)
+ *   rbf_eval                (no reference code) s(y) = sum_j w_j phi(|y-x_j|)
+ */
+#ifndef GSL_SINTERP_HIP_H
+#define GSL_SINTERP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gsl_sinterp_hip_ctx gsl_sinterp_hip_ctx;
+
+/* radial kernels */
+#define GSL_SINTERP_RBF_GAUSSIAN 0 /* phi(r) = exp(-(eps r)^2)                      */
+#define GSL_SINTERP_RBF_TPS 1      /* phi(r) = r^2 ln r = 0.5 r^2 ln r^2, phi(0)=0  */
+
+/* ---- context / memory --------------------------------------------------- */
+int gsl_sinterp_hip_device_count(void); /* 0 when no GPU is visible */
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream), or
+   NULL to let the context create and own one. */
+int gsl_sinterp_hip_ctx_create(gsl_sinterp_hip_ctx **ctx, int device, void *stream);
+void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx);
+int gsl_sinterp_hip_sync(gsl_sinterp_hip_ctx *ctx);
+const char *gsl_sinterp_hip_last_error(const gsl_sinterp_hip_ctx *ctx);
+int gsl_sinterp_hip_malloc(gsl_sinterp_hip_ctx *ctx, void **d_ptr, size_t bytes);
+int gsl_sinterp_hip_free(gsl_sinterp_hip_ctx *ctx, void *d_ptr);
+int gsl_sinterp_hip_h2d(gsl_sinterp_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int gsl_sinterp_hip_d2h(gsl_sinterp_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* hipEvent pair on the context's stream (bench / roofline timing) */
+int gsl_sinterp_hip_timer_start(gsl_sinterp_hip_ctx *ctx);
+int gsl_sinterp_hip_timer_stop(gsl_sinterp_hip_ctx *ctx, float *h_ms);
+
+/* ---- barycentric evaluation over a host-built Delaunay history DAG ------- */
+/* One 64-byte record per DAG node (see DESIGN.md "HBM layout"). */
+#define GSL_SINTERP_TREE_RECORD_BYTES 64
+#define GSL_SINTERP_TREE_LEAFTAB_BYTES 32
+
+/* Build the node records on the device.  d_type[n_nodes] (0 leaf, 1 sub_{d+1},
+   2 sub_d), d_pidx/d_links [3*n_nodes] exactly as the reference keeps them
+   (linear_simplex.h:31-59), d_points [2*n_points] in INSERTION order
+   (row shuffle[i] of the data matrix), h_geom[10] = seed_points(3x2, row-major),
+   shift(2), scale(2).  The per-node 2x2 LU is computed with the reference's
+   operation sequence (no FMA contraction) so it is bit-identical to the host. */
+int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type,
+                              const int *d_pidx, const int *d_links, int n_points,
+                              const double *d_points, const double *h_geom, void *d_records);
+/* Per-node table of the three vertex responses (+ seed mask); d_response is in
+   insertion order (response[shuffle[i]]). */
+int gsl_sinterp_hip_tree_bind(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_pidx,
+                              int n_points, const double *d_response, void *d_leaftab);
+/* Locate + interpolate m targets (row k at d_targets + k*ttda).  d_leaf may be
+   NULL.  Target outside the cage: leaf = -1, value = NaN, and *h_n_outside
+   (may be NULL; forces a sync when given) counts them -> GSL_EDOM. */
+int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_records,
+                              const void *d_leaftab, const double *h_scale,
+                              const double *d_targets, size_t m, size_t ttda, double *d_values,
+                              int *d_leaf, long long *h_n_outside);
+
+/* ---- RBF: fill, dense solve, evaluation sweep ----------------------------- */
+int gsl_sinterp_hip_rbf_fill(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x,
+                             size_t n, int dim, size_t xtda, double *d_phi, size_t lda);
+/* In-place A = L L^T, L in the lower triangle, original A kept in the strict
+   upper triangle; *h_info = 0, or j+1 when pivot j <= 0 (-> GSL_EDOM). */
+int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda,
+                                     int *h_info);
+int gsl_sinterp_hip_cholesky_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt,
+                                 size_t lda, double *d_x);
+/* PA = LU with partial pivoting; d_perm[n] (int32) as gsl_permutation content. */
+int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda,
+                              int *d_perm, int *h_signum);
+int gsl_sinterp_hip_lu_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_lu, size_t lda,
+                           const int *d_perm, double *d_x);
+int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x,
+                             size_t n, int dim, size_t xtda, const double *d_w,
+                             const double *d_y, size_t m, size_t ytda, double *d_s);
+
+/* ---- synthetic clouds generated in HBM (bench / tests) ------- */
+int gsl_sinterp_hip_synth_unit(gsl_sinterp_hip_ctx *ctx, uint64_t seed, uint64_t first,
+                               double offset, double span, double *d_out, size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

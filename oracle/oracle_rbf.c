@@ -1,0 +1,71 @@
+/*
+ * oracle_rbf.c -- TEST INFRASTRUCTURE (see oracle.h).
+ *
+ * RBF interpolation is NOT implemented in the reference (README:18-26 lists it
+ * as future work), so this harness is the composition SURVEY.md 3.3/3.4 fixes:
+ *   fill   Phi_ij = phi(|x_i - x_j|) with libm exp/log           (no reference code)
+ *   solve  Gaussian: gsl_linalg_cholesky_decomp1 + _svx          (linalg/cholesky.c:88,163)
+ *          TPS:      gsl_linalg_LU_decomp + _svx (not SPD)       (linalg/lu.c:59,166)
+ *   eval   s(y) = sum_j w_j phi(|y - x_j|), j ascending          (no reference code)
+ * The RBF kernels are therefore "parity unpinned" by any reference test; the
+ * solvers underneath are pinned (tests/test_oracle_linalg.py).
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+double oracle_rbf_phi(int kind, double eps, double r2)
+{
+  if (kind == ORACLE_RBF_GAUSSIAN) return exp(-(eps * eps) * r2);
+  if (r2 == 0.0) return 0.0;
+  return 0.5 * r2 * log(r2);
+}
+
+static double dist2(const double *a, const double *b, int dim)
+{
+  double s = 0.0;
+  for (int c = 0; c < dim; c++) { double d = a[c] - b[c]; s += d * d; }
+  return s;
+}
+
+void oracle_rbf_fill(int kind, double eps, const double *x, size_t n, int dim, size_t tda,
+                     double *phi, size_t lda)
+{
+  for (size_t i = 0; i < n; i++)
+    for (size_t j = 0; j < n; j++)
+      phi[i * lda + j] = oracle_rbf_phi(kind, eps, dist2(x + i * tda, x + j * tda, dim));
+}
+
+int oracle_rbf_solve(int kind, double eps, const double *x, size_t n, int dim, size_t tda,
+                     const double *f, double *w)
+{
+  double *phi = (double *)malloc(n * n * sizeof(double));
+  if (!phi) return ORACLE_FAILURE;
+  oracle_rbf_fill(kind, eps, x, n, dim, tda, phi, n);
+  memcpy(w, f, n * sizeof(double));
+  int status;
+  if (kind == ORACLE_RBF_GAUSSIAN) {
+    status = oracle_cholesky_decomp1(n, phi, n);
+    if (status == ORACLE_SUCCESS) status = oracle_cholesky_svx(n, phi, n, w);
+  } else {
+    size_t *perm = (size_t *)malloc(n * sizeof(size_t));
+    int signum;
+    status = oracle_lu_decomp(n, phi, n, perm, &signum);
+    if (status == ORACLE_SUCCESS) status = oracle_lu_svx(n, phi, n, perm, w);
+    free(perm);
+  }
+  free(phi);
+  return status;
+}
+
+void oracle_rbf_eval(int kind, double eps, const double *x, size_t n, int dim, size_t tda,
+                     const double *w, const double *y, size_t m, size_t ytda, double *s)
+{
+  for (size_t k = 0; k < m; k++) {
+    double acc = 0.0;
+    for (size_t j = 0; j < n; j++)
+      acc += w[j] * oracle_rbf_phi(kind, eps, dist2(y + k * ytda, x + j * tda, dim));
+    s[k] = acc;
+  }
+}
