@@ -98,6 +98,7 @@ SIGNATURES = {
     # --- include/gsl_sinterp_hip.h
     "gsl_sinterp_hip_device_count": (_i, []),
     "gsl_sinterp_hip_ctx_create": (_i, [C.POINTER(_vp), _i, _vp]),
+    "gsl_sinterp_hip_ctx_own_stream": (_i, [_vp]),
     "gsl_sinterp_hip_ctx_destroy": (None, [_vp]),
     "gsl_sinterp_hip_sync": (_i, [_vp]),
     "gsl_sinterp_hip_last_error": (C.c_char_p, [_vp]),
@@ -116,6 +117,7 @@ SIGNATURES = {
     "gsl_sinterp_hip_lu_decomp": (_i, [_vp, _sz, _vp, _sz, _vp, _pi]),
     "gsl_sinterp_hip_lu_svx": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "gsl_sinterp_hip_rbf_eval": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp]),
+    "gsl_sinterp_hip_gemm_minus": (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _vp, _sz, _i, _vp, _sz, _i]),
     "gsl_sinterp_hip_synth_unit": (_i, [_vp, C.c_uint64, C.c_uint64, _d, _d, _vp, _sz]),
     # --- include/gsl_sinterp.h part 1 (reference symbols)
     "simplex_tree_node_alloc": (_i, [_pt]),
@@ -184,9 +186,10 @@ def _ptr(symbol):
 # ------------------------------------------------------------------ views
 def as_matrix(a):
     """gsl_matrix view of a 2-D float64 numpy array (row stride honoured)."""
-    assert a.dtype == np.float64 and a.ndim == 2 and a.strides[1] == 8
+    assert a.dtype == np.float64 and a.ndim == 2 and (a.size == 0 or a.strides[1] == 8)
     m = gsl_matrix()
-    m.size1, m.size2, m.tda = a.shape[0], a.shape[1], a.strides[0] // 8
+    m.size1, m.size2 = a.shape[0], a.shape[1]
+    m.tda = a.strides[0] // 8 if a.shape[0] > 1 and a.size else max(a.shape[1], 1)
     m.data = a.ctypes.data_as(_pd)
     m.block, m.owner = None, 0
     m._keep = a
@@ -293,6 +296,10 @@ class HipContext:
 
     def rbf_eval(self, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s):
         check(lib().gsl_sinterp_hip_rbf_eval(self._h, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s), self._h)
+
+    def gemm_minus(self, m, n, k, d_a, lda, d_b, ldb, b_is_kn, d_c, ldc, lower_only=0):
+        check(lib().gsl_sinterp_hip_gemm_minus(self._h, m, n, k, d_a, lda, d_b, ldb, b_is_kn, d_c, ldc, lower_only),
+              self._h)
 
     def synth_unit(self, seed, first, offset, span, d_out, count):
         check(lib().gsl_sinterp_hip_synth_unit(self._h, seed, first, offset, span, d_out, count), self._h)

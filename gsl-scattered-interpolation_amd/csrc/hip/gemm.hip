@@ -176,3 +176,13 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   LAUNCH_CHECK(ctx);
   return ST_SUCCESS;
 }
+
+extern "C" int gsl_sinterp_hip_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, const double *d_a,
+                                          size_t lda, const double *d_b, size_t ldb, int b_is_kn, double *d_c,
+                                          size_t ldc, int lower_only)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, lda >= k && ldc >= n && ldb >= (b_is_kn ? n : k), ST_EINVAL);
+  REQUIRE(ctx, (m == 0 || n == 0 || k == 0) || (d_a && d_b && d_c), ST_EFAULT);
+  return sinterp_gemm_minus(ctx, m, n, k, d_a, lda, d_b, ldb, b_is_kn, d_c, ldc, lower_only);
+}

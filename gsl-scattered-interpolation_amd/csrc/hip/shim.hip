@@ -23,11 +23,10 @@ extern "C" int gsl_sinterp_hip_ctx_create(gsl_sinterp_hip_ctx **out, int device,
   memset(ctx, 0, sizeof *ctx);
   ctx->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete ctx; return ST_EFAILED; }
-  if (stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = 0; }
-  else {
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ST_EFAILED; }
-    ctx->owns_stream = 1;
-  }
+  /* NULL = the device's default (null) stream: ordered after everything the
+     caller already enqueued there (hipMemcpy, torch's default stream, ...). */
+  ctx->stream = (hipStream_t)stream;
+  ctx->owns_stream = 0;
   ctx->scratch_bytes = 4096;
   if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipMalloc(&ctx->d_scratch, ctx->scratch_bytes) != hipSuccess) {
@@ -38,11 +37,24 @@ extern "C" int gsl_sinterp_hip_ctx_create(gsl_sinterp_hip_ctx **out, int device,
   return ST_SUCCESS;
 }
 
+extern "C" int gsl_sinterp_hip_ctx_own_stream(gsl_sinterp_hip_ctx *ctx)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  if (ctx->owns_stream) return ST_SUCCESS;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  hipStream_t s;
+  HIP_OK(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  ctx->stream = s;
+  ctx->owns_stream = 1;
+  return ST_SUCCESS;
+}
+
 extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
 {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

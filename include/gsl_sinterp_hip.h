@@ -39,9 +39,12 @@ typedef struct gsl_sinterp_hip_ctx gsl_sinterp_hip_ctx;
 
 /* ---- context / memory --------------------------------------------------- */
 int gsl_sinterp_hip_device_count(void); /* 0 when no GPU is visible */
-/* stream: a hipStream_t owned by the caller (e.g. torch's current stream), or
-   NULL to let the context create and own one. */
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream); NULL is
+   the device's default stream, i.e. ordered with the caller's other default-stream
+   work.  ctx_own_stream switches the context to a private non-blocking stream
+   (for overlap with other streams; the caller then orders work explicitly). */
 int gsl_sinterp_hip_ctx_create(gsl_sinterp_hip_ctx **ctx, int device, void *stream);
+int gsl_sinterp_hip_ctx_own_stream(gsl_sinterp_hip_ctx *ctx);
 void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx);
 int gsl_sinterp_hip_sync(gsl_sinterp_hip_ctx *ctx);
 const char *gsl_sinterp_hip_last_error(const gsl_sinterp_hip_ctx *ctx);
@@ -96,6 +99,15 @@ int gsl_sinterp_hip_lu_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_l
 int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x,
                              size_t n, int dim, size_t xtda, const double *d_w,
                              const double *d_y, size_t m, size_t ytda, double *d_s);
+
+/* Level-3 building block of both factorisations, exposed for tests and roofline
+   measurement (role of gsl_blas_dgemm / dsyrk, blas/blas.c:1334,1649):
+     C[m x n] -= A[m x k] * B^T  (b_is_kn = 0, B stored [n][k])
+     C[m x n] -= A[m x k] * B    (b_is_kn = 1, B stored [k][n])
+   lower_only != 0: C is square and only its lower triangle is updated. */
+int gsl_sinterp_hip_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, const double *d_a,
+                               size_t lda, const double *d_b, size_t ldb, int b_is_kn, double *d_c,
+                               size_t ldc, int lower_only);
 
 /* ---- synthetic clouds generated in HBM (bench / tests) ------- */
 int gsl_sinterp_hip_synth_unit(gsl_sinterp_hip_ctx *ctx, uint64_t seed, uint64_t first,

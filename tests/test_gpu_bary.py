@@ -1,0 +1,147 @@
+"""-m gpu: barycentric HIP path vs the CPU oracle, through the C-ABI.
+
+Bar: leaf indices and values BIT-EXACT (int32 / fp64 bit patterns)."""
+import numpy as np
+import pytest
+
+from gpu_util import bits, dev, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def build_pair(pkg, orc, x, flags=0, seeded=True):
+    n = len(x)
+    t = pkg.SimplexTree(2, n)
+    assert t.init(x, flags=flags, rng=pkg.capi.Rng(0) if seeded else None) == 0
+    o = orc.Tree(2, n)
+    assert o.init(x, flags=flags, seed=0 if seeded else None) == 0
+    return t, o
+
+
+@pytest.mark.parametrize("n,m,flags", [(8, 500, 0), (512, 20000, 0), (4096, 100000, 0), (4096, 50000, 1), (4096, 50000, 2)])
+def test_bary_matches_oracle_bitexact(pkg, orc, n, m, flags):
+    scale, off = np.array([3.0, 0.5]), np.array([-1.0, 10.0])
+    x = orc.synth_centres(n, 2) * scale + off
+    f = orc.synth_response(x)
+    y = orc.synth_targets(0, m, 2) * scale + off
+    t, o = build_pair(pkg, orc, x, flags)
+    d = t.device_alloc(0)
+    assert d.set_response(f) == 0
+    st, vals, leaf = d.eval_many(y)
+    ovals, oleaf = o.eval_many(x, f, y)
+    assert st == 0
+    assert np.array_equal(leaf, oleaf)
+    assert np.array_equal(bits(vals), bits(ovals))
+
+
+def test_bary_weather_golden(pkg, weather):
+    """survey-captured outputs of the reference (tests/golden/survey_known_answers.json), cfg1."""
+    import json, os
+    spec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_known_answers.json")))["configs"]["cfg1"]
+    data = weather[:, :2]
+    t = pkg.SimplexTree(2, 50)
+    assert t.init(data, flags=0, rng=pkg.capi.Rng(0)) == 0
+    d = t.device_alloc(0)
+    assert d.set_response(weather[:, 2]) == 0            # stride-3 response column
+    y = np.array([q["point"] for q in spec["queries"]], dtype=np.float64)
+    st, vals, leaf = d.eval_many(y)
+    assert st == 0
+    assert list(leaf) == [q["leaf"] for q in spec["queries"]]
+    assert [float(v) for v in vals] == [float(q["value"]) for q in spec["queries"]]
+
+
+def test_bary_edge_cases(pkg, orc):
+    n = 1000
+    x = orc.synth_centres(n, 2)
+    f = orc.synth_response(x)
+    t, o = build_pair(pkg, orc, x)
+    d = t.device_alloc(0)
+    assert d.set_response(f) == 0
+    # targets ON data points, on edge midpoints, outside the hull (cage region) and outside the cage
+    mids = 0.5 * (x[:-1] + x[1:])
+    hull_out = np.array([[-5.0, 0.5], [0.5, 7.0], [30.0, 30.0]])
+    y = np.concatenate([x[:200], mids[:200], hull_out])
+    st, vals, leaf = d.eval_many(y)
+    ovals, oleaf = o.eval_many(x, f, y)
+    assert st == 0 and np.array_equal(leaf, oleaf) and np.array_equal(bits(vals), bits(ovals))
+    far = np.array([[0.5, 0.5], [1e9, -1e9], [0.25, 0.75]])
+    st, vals, leaf = d.eval_many(far)
+    assert st == pkg.capi.GSL_EDOM and leaf[1] == -1 and np.isnan(vals[1])     # q7: reported, not aborted
+    assert leaf[0] >= 0 and leaf[2] >= 0 and not np.isnan(vals[[0, 2]]).any()
+    # empty batch
+    st, vals, leaf = d.eval_many(np.zeros((0, 2)))
+    assert st == 0 and len(vals) == 0
+    # ragged target layout: rows of a wider matrix (tda = 5)
+    wide = np.zeros((300, 5)); wide[:, :2] = orc.synth_targets(7, 300, 2)
+    st, vals, leaf = d.eval_many(wide[:, :2])
+    ovals, oleaf = o.eval_many(x, f, np.ascontiguousarray(wide[:, :2]))
+    assert st == 0 and np.array_equal(leaf, oleaf) and np.array_equal(bits(vals), bits(ovals))
+
+
+def test_bary_empty_cage_interpolates_zero(pkg):
+    """scattered_interp_example.c:51-52 on the device path."""
+    t = pkg.SimplexTree(2, 4)
+    assert t.init(None, flags=pkg.capi.TREE_NOSTANDARDIZE) == 0
+    d = t.device_alloc(0)
+    assert d.set_response(np.zeros(0)) == 0
+    st, vals, leaf = d.eval_many(np.array([[-88.0, 41.0], [0.0, 0.0]]))
+    assert st == 0 and list(leaf) == [0, 0] and list(vals) == [0.0, 0.0]
+
+
+def test_bary_resident_full_size_properties(pkg, orc):
+    """C5 shape (N = 50 000, M = 10^6 here, 10^7 in bench): size-independent properties --
+    linear reproduction, value bounds, sampled bit-exactness vs the oracle."""
+    import torch
+    n, m = 50000, 1_000_000
+    x = orc.synth_centres(n, 2)
+    g = 2 * x[:, 0] - 3 * x[:, 1] + 0.5
+    t, o = build_pair(pkg, orc, x)
+    d = t.device_alloc(0)
+    assert d.set_response(g) == 0
+    ctx = pkg.HipContext.on_torch_stream(0)
+    ty = torch.empty((m, 2), dtype=torch.float64, device="cuda")
+    ctx.synth_unit(0xC0FFEE02, 0, 0.02, 0.96, ptr(ty), 2 * m)
+    ctx.sync()
+    yh = ty.cpu().numpy()
+    assert np.array_equal(bits(yh[:1000]), bits(orc.synth_targets(0, 1000, 2)))   # same cloud on both sides
+    tv = torch.empty(m, dtype=torch.float64, device="cuda")
+    tl = torch.empty(m, dtype=torch.int32, device="cuda")
+    assert d.eval_resident(ptr(ty), m, 2, ptr(tv), ptr(tl)) == 0
+    torch.cuda.synchronize()
+    lib_ctx = pkg.lib().simplex_tree_device_ctx(d._h)
+    assert pkg.lib().gsl_sinterp_hip_sync(lib_ctx) == 0
+    vals, leaf = tv.cpu().numpy(), tl.cpu().numpy()
+    assert np.abs(vals - (2 * yh[:, 0] - 3 * yh[:, 1] + 0.5)).max() < 5e-15
+    ty_, _, _ = t.arrays()
+    assert (ty_[leaf] == 0).all()                                       # every result is a leaf
+    idx = np.arange(0, m, 97)
+    ovals, oleaf = o.eval_many(x, g, np.ascontiguousarray(yh[idx]))
+    assert np.array_equal(leaf[idx], oleaf) and np.array_equal(bits(vals[idx]), bits(ovals))
+
+
+def test_lowlevel_pack_matches_host_records(pkg, orc):
+    """tree_pack on raw device arrays (the multi-GPU broadcast path) == records built via the host API."""
+    import torch
+    n, m = 3000, 30000
+    x = orc.synth_centres(n, 2)
+    f = orc.synth_response(x)
+    t, o = build_pair(pkg, orc, x)
+    types, pidx, links = t.arrays()
+    sh = t.shuffle()
+    ctx = pkg.HipContext.on_torch_stream(0)
+    nn = t.n_nodes
+    d_type, d_pidx, d_links = dev(types), dev(pidx), dev(links)
+    d_pts, d_resp = dev(x[sh]), dev(f[sh])
+    rec = torch.empty(nn * 64, dtype=torch.uint8, device="cuda")
+    tab = torch.empty(nn * 32, dtype=torch.uint8, device="cuda")
+    geom = t.geom()
+    ctx.tree_pack(nn, ptr(d_type), ptr(d_pidx), ptr(d_links), n, ptr(d_pts), geom, ptr(rec))
+    ctx.tree_bind(nn, ptr(d_pidx), n, ptr(d_resp), ptr(tab))
+    y = orc.synth_targets(0, m, 2)
+    d_y = dev(y)
+    d_v = torch.empty(m, dtype=torch.float64, device="cuda")
+    d_l = torch.empty(m, dtype=torch.int32, device="cuda")
+    outside = ctx.bary_eval(nn, ptr(rec), ptr(tab), geom[8:10], ptr(d_y), m, 2, ptr(d_v), ptr(d_l), count_outside=True)
+    ovals, oleaf = o.eval_many(x, f, y)
+    assert outside == 0
+    assert np.array_equal(d_l.cpu().numpy(), oleaf) and np.array_equal(bits(d_v.cpu().numpy()), bits(ovals))

@@ -1,0 +1,116 @@
+"""-m gpu: blocked fp64-MFMA Cholesky / LU and the triangular sweeps vs the reference-order
+unblocked CPU oracle, plus the reference's own Hilbert / Vandermonde known answers."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, ptr
+
+pytestmark = pytest.mark.gpu
+EPS = 2.2204460492503131e-16
+LINALG = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_linalg_known_answers.json")))
+
+
+def spd(n, seed):
+    rng = np.random.default_rng(seed)
+    m = rng.random((n, n))
+    return np.tril(m) + np.tril(m, -1).T + 10.0 * n * np.eye(n)      # linalg/test_common.c:68-88
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 64, 100, 257, 1000, 2048, 3000])
+def test_cholesky_decomp_and_solve(pkg, orc, n):
+    a = spd(n, n)
+    b = np.arange(1, n + 1, dtype=np.float64)
+    ctx = pkg.HipContext.on_torch_stream(0)
+    lda = n + (3 if n % 2 else 2)                                      # tda > size2 honoured
+    d_a = torch.zeros((n, lda), dtype=torch.float64, device="cuda")
+    d_a[:, :n] = dev(a)
+    st, info = ctx.cholesky_decomp1(n, ptr(d_a), lda)
+    assert st == 0 and info == 0
+    got = d_a.cpu().numpy()[:, :n]
+    st_o, want = orc.cholesky_decomp1(a)
+    L, Lo = np.tril(got), np.tril(want)
+    assert np.abs(L - Lo).max() <= 1e-12 * np.abs(Lo).max()
+    assert np.array_equal(np.triu(got, 1), np.triu(a, 1))             # original kept above the diagonal
+    rec = L @ L.T
+    if n <= 64:
+        assert np.all(np.abs(rec - a) <= 100.0 * n * EPS * np.abs(a))  # linalg/test_cholesky.c:59-135 (N <= 50 there)
+    assert np.abs(rec - a).max() <= 10.0 * EPS * np.abs(a).max()        # norm-wise backward error at any N
+    d_x = dev(b)
+    ctx.cholesky_svx(n, ptr(d_a), lda, ptr(d_x))
+    ctx.sync()
+    x = d_x.cpu().numpy()
+    xo = orc.cholesky_solve(want, b)
+    assert np.abs(x - xo).max() <= 1e-11 * np.abs(xo).max()
+
+
+def test_cholesky_rejects_indefinite(pkg):
+    ctx = pkg.HipContext.on_torch_stream(0)
+    n = 200
+    a = spd(n, 1)
+    a[150, 150] = -1.0
+    d_a = dev(a)
+    st, info = ctx.cholesky_decomp1(n, ptr(d_a), n)
+    assert st == pkg.capi.GSL_EDOM and info == 151
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 12])
+def test_hilbert_known_answers(pkg, n):
+    """linalg/test.c:378-398 exact solutions with the reference's tolerances, on the GPU path."""
+    i = np.arange(n)
+    h = 1.0 / (i[:, None] + i[None, :] + 1.0)
+    rhs = np.arange(1, n + 1, dtype=np.float64)
+    spec = LINALG["hilbert"][str(n)]
+    ctx = pkg.HipContext.on_torch_stream(0)
+
+    def ok(x, tol):
+        return all(x[k] == spec["solution"][k] or abs(x[k] - spec["solution"][k]) / abs(spec["solution"][k]) <= tol
+                   for k in range(n))
+    d_a, d_x = dev(h), dev(rhs)
+    st, info = ctx.cholesky_decomp1(n, ptr(d_a), n)
+    assert st == 0
+    ctx.cholesky_svx(n, ptr(d_a), n, ptr(d_x)); ctx.sync()
+    assert ok(d_x.cpu().numpy(), spec["chol_eps_mult"] * EPS if "chol_eps_mult" in spec else spec["chol_abs_tol"])
+    d_a, d_x = dev(h), dev(rhs)
+    d_p = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.lu_decomp(n, ptr(d_a), n, ptr(d_p))
+    assert ctx.lu_svx(n, ptr(d_a), n, ptr(d_p), ptr(d_x)) == 0
+    ctx.sync()
+    assert ok(d_x.cpu().numpy(), spec["lu_eps_mult"] * EPS if "lu_eps_mult" in spec else spec["lu_abs_tol"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 33, 100, 255, 1024, 2000])
+def test_lu_decomp_and_solve(pkg, orc, n):
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n, n))
+    b = rng.standard_normal(n)
+    ctx = pkg.HipContext.on_torch_stream(0)
+    lda = n + 2
+    d_a = torch.zeros((n, lda), dtype=torch.float64, device="cuda")
+    d_a[:, :n] = dev(a)
+    d_p = torch.zeros(n, dtype=torch.int32, device="cuda")
+    signum = ctx.lu_decomp(n, ptr(d_a), lda, ptr(d_p))
+    lu, perm = d_a.cpu().numpy()[:, :n], d_p.cpu().numpy()
+    lu_o, perm_o, sg_o = orc.lu_decomp(a)
+    assert np.array_equal(perm, perm_o.astype(np.int64)) and signum == sg_o      # same pivot sequence
+    Lm, U = np.tril(lu, -1) + np.eye(n), np.triu(lu)
+    assert np.abs(Lm @ U - a[perm]).max() <= 1e-13 * n * np.abs(a).max()
+    assert np.abs(lu - lu_o).max() <= 1e-9 * np.abs(lu_o).max()
+    d_x = dev(b)
+    assert ctx.lu_svx(n, ptr(d_a), lda, ptr(d_p), ptr(d_x)) == 0
+    ctx.sync()
+    st, xo = orc.lu_solve(lu_o, perm_o, b)
+    x = d_x.cpu().numpy()
+    assert np.abs(a @ x - b).max() <= 1e-10 * max(1.0, np.abs(x).max()) * n
+    assert np.abs(x - xo).max() <= 1e-7 * np.abs(xo).max()
+
+
+def test_lu_singular_reports_edom(pkg):
+    ctx = pkg.HipContext.on_torch_stream(0)
+    a = np.ones((4, 4))
+    d_a, d_p, d_x = dev(a), torch.zeros(4, dtype=torch.int32, device="cuda"), dev(np.ones(4))
+    ctx.lu_decomp(4, ptr(d_a), 4, ptr(d_p))
+    assert ctx.lu_svx(4, ptr(d_a), 4, ptr(d_p), ptr(d_x)) == pkg.capi.GSL_EDOM     # lu.c:181-184

@@ -1,0 +1,97 @@
+"""-m gpu: RBF fill / solve / eval on the HIP path vs the CPU oracle (libm + reference-order
+unblocked solvers + naive j-ascending sums).  fp64 tolerance: 1e-10 relative (north star);
+the RBF kernels themselves are 'parity unpinned' by any reference test (README:18-26)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, ptr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("kind,dim,n", [(0, 2, 512), (0, 3, 700), (1, 2, 512), (0, 1, 130), (1, 3, 333)])
+def test_fill_matches_oracle(pkg, orc, kind, dim, n):
+    x = orc.synth_centres(n, dim)
+    eps = orc.gaussian_eps(n, dim)
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_x = dev(x)
+    phi = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    ctx.rbf_fill(kind, eps, ptr(d_x), n, dim, dim, ptr(phi), n)
+    got = phi.cpu().numpy()
+    want = orc.rbf_fill(kind, eps, x)
+    # O(1) entries; r^2 is accumulated with FMA on the device, so a few ulp (not bit-equal to libm)
+    assert np.abs(got - want).max() <= 2e-15 * max(1.0, np.abs(want).max())
+    assert np.array_equal(got, got.T)                                              # bitwise symmetric
+    if kind == 1:
+        assert (np.diag(got) == 0).all()                                           # phi(0) = 0
+
+
+@pytest.mark.parametrize("kind,dim,n,m", [(0, 2, 512, 10000), (1, 2, 512, 10000), (0, 3, 1000, 5000), (0, 2, 2048, 3000),
+                                          (1, 2, 1500, 3000)])
+def test_facade_rbf_matches_oracle(pkg, orc, kind, dim, n, m):
+    """C1 (N=512 Gaussian, M=10^4) and friends through gsl_sinterp alloc/init/eval_many."""
+    x = orc.synth_centres(n, dim)
+    f = orc.synth_response(x)
+    y = orc.synth_targets(0, m, dim)
+    eps = orc.gaussian_eps(n, dim)
+    s = pkg.Sinterp("gaussian" if kind == 0 else "tps", dim, n, 0)
+    assert s.init(x, f) == 0
+    st, got, _ = s.eval_many(y)
+    assert st == 0
+    w = orc.rbf_solve(kind, eps, x, f)
+    want = orc.rbf_eval(kind, eps, x, w, y)
+    assert relerr(got, want) < TOL
+    st, gw = s.weights()
+    assert st == 0
+    if kind == 0:
+        assert relerr(gw, w) < TOL                      # Gaussian weights too (kappa <~ 2e4)
+    # the interpolant reproduces the data at the centres
+    st, at_centres, _ = s.eval_many(x)
+    assert relerr(at_centres, f) < 1e-9
+    # single-point entry agrees with the batch
+    st1, v1 = s.eval_e(y[0])
+    assert st1 == 0 and abs(v1 - got[0]) <= 1e-13 * max(1.0, abs(got[0]))
+
+
+def test_eval_linearity_and_layout(pkg, orc):
+    """size-independent properties at a larger M: linear in the weights; ragged strides honoured."""
+    n, m, dim = 1024, 300000, 2
+    x = orc.synth_centres(n, dim)
+    eps = orc.gaussian_eps(n, dim)
+    rng = np.random.default_rng(3)
+    w1, w2 = rng.standard_normal(n), rng.standard_normal(n)
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_x = dev(x)
+    d_y = torch.empty((m, 3), dtype=torch.float64, device="cuda")          # ytda = 3 > dim
+    ctx.synth_unit(0xC0FFEE02, 0, 0.02, 0.96, ptr(d_y), 3 * m)
+    outs = []
+    for w in (w1, w2, 2.0 * w1 - 0.5 * w2):
+        d_w = dev(w)
+        d_s = torch.empty(m, dtype=torch.float64, device="cuda")
+        ctx.rbf_eval(0, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), m, 3, ptr(d_s))
+        ctx.sync()
+        outs.append(d_s.cpu().numpy())
+    assert np.abs(outs[2] - (2.0 * outs[0] - 0.5 * outs[1])).max() < 1e-11 * np.abs(outs[2]).max()
+    yh = d_y.cpu().numpy()[:2000, :2]
+    want = orc.rbf_eval(0, eps, x, w1, np.ascontiguousarray(yh))
+    assert relerr(outs[0][:2000], want) < TOL
+
+
+def test_facade_errors(pkg, orc):
+    n = 64
+    x = orc.synth_centres(n, 2)
+    x[5] = x[4]                                          # duplicate centre: Gaussian matrix singular
+    s = pkg.Sinterp("gaussian", 2, n, 0)
+    st = s.init(x, orc.synth_response(x))
+    assert st == pkg.capi.GSL_EDOM                       # cholesky.c:120-123 semantics
+    s2 = pkg.Sinterp("gaussian", 2, n, 0)
+    x = orc.synth_centres(n, 2)
+    assert s2.init(x, orc.synth_response(x)) == 0
+    st, vals, _ = s2.eval_many(np.zeros((0, 2)))
+    assert st == 0 and len(vals) == 0
