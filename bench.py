@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the scattered-interpolation hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5|C1]
+
+One "step" = one full pass of the hot path over one batch of synthetic input that is
+already resident in HBM (SURVEY.md 8(d) clouds, generated on the device):
+  RBF configs (C1-C4): Phi fill -> dense factorisation -> two triangular solves (rank 0)
+                       -> RCCL broadcast of the weight vector -> N x M evaluation sweep of
+                          this rank's shard of targets
+  barycentric (C5):    locate + interpolate this rank's shard over the (host-built, already
+                       mirrored) Delaunay history DAG
+`value` = targets interpolated by all ranks per second of step time (max over ranks), in
+M points/s.  Default workload = BASELINE.json configs[1] (C2: 2-D, N=4096 TPS, M=1M per GPU).
+
+For N > 1 the driver launches this file with torch.distributed.run (one rank per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix = vector peak; 256 CU x 128 flop/clk x 2.4 GHz
+
+CONFIGS = {
+    # name: (kind, dim, n_centres, m_targets, sharding)   sharding: per_gpu = weak, total = strong
+    "C1": dict(kind="gaussian", dim=2, n=512, m=10_000, shard="per_gpu",
+               label="C1: 2-D N=512 Gaussian RBF, M=10k targets"),
+    "C2": dict(kind="tps", dim=2, n=4096, m=1_000_000, shard="per_gpu",
+               label="C2: 2-D N=4096 thin-plate-spline RBF, M=1M targets per GPU"),
+    "C3": dict(kind="gaussian", dim=3, n=16384, m=1_000_000, shard="per_gpu",
+               label="C3: 3-D N=16384 Gaussian RBF (16k x 16k fp64 Cholesky), M=1M targets per GPU"),
+    "C4": dict(kind="gaussian", dim=2, n=8192, m=10_000_000, shard="total",
+               label="C4: 2-D N=8192 Gaussian RBF, M=10M targets sharded over the GPUs"),
+    "C5": dict(kind="bary", dim=2, n=50_000, m=10_000_000, shard="total",
+               label="C5: 2-D N=50000 barycentric over host-built Delaunay DAG, M=10M targets sharded"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+
+    pkg = g.load_package()
+    cfg = CONFIGS[args.config]
+    ctx = pkg.HipContext.on_torch_stream(local_rank)
+    dim, n = cfg["dim"], cfg["n"]
+    m_rank = cfg["m"] if cfg["shard"] == "per_gpu" else (cfg["m"] + world - 1) // world
+    first = rank * m_rank
+    if cfg["shard"] == "total":
+        m_rank = max(0, min(m_rank, cfg["m"] - first))
+    m_total = m_rank * world if cfg["shard"] == "per_gpu" else cfg["m"]
+
+    f64 = torch.float64
+    # ---- synthetic inputs, generated in HBM (same generator as oracle/oracle_synth.c)
+    d_x = torch.empty((n, dim), dtype=f64, device="cuda")
+    d_y = torch.empty((m_rank, dim), dtype=f64, device="cuda")
+    d_s = torch.empty(m_rank, dtype=f64, device="cuda")
+    ctx.synth_unit(0xC0FFEE01, 0, 0.0, 1.0, d_x.data_ptr(), n * dim)
+    ctx.synth_unit(0xC0FFEE02, first * dim, 0.02, 0.96, d_y.data_ptr(), m_rank * dim)
+    d_f = torch.zeros(n, dtype=f64, device="cuda")
+    for c in range(dim):
+        d_f += torch.sin(3.0 * (c + 1) * d_x[:, c])
+    torch.cuda.synchronize()
+
+    phases = {}
+
+    def timed(name, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        phases.setdefault(name, []).append((e0, e1))
+
+    if cfg["kind"] == "bary":
+        # host-built triangulation (one-off, not part of the step), mirrored once into HBM
+        xh = d_x.cpu().numpy()
+        fh = d_f.cpu().numpy()
+        t0 = time.time()
+        tree = pkg.SimplexTree(2, n)
+        assert tree.init(xh, flags=0, rng=pkg.capi.Rng(0)) == 0
+        build_s = time.time() - t0
+        nn = tree.n_nodes
+        rec = torch.empty(nn * 64, dtype=torch.uint8, device="cuda")
+        tab = torch.empty(nn * 32, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            types, pidx, links = tree.arrays()
+            sh = tree.shuffle()
+            d_type, d_pidx, d_links = (torch.from_numpy(a).cuda() for a in (types, pidx, links))
+            d_pts, d_resp = torch.from_numpy(xh[sh]).cuda(), torch.from_numpy(fh[sh]).cuda()
+            ctx.tree_pack(nn, d_type.data_ptr(), d_pidx.data_ptr(), d_links.data_ptr(), n, d_pts.data_ptr(),
+                          tree.geom(), rec.data_ptr())
+            ctx.tree_bind(nn, d_pidx.data_ptr(), n, d_resp.data_ptr(), tab.data_ptr())
+        if world > 1:                                    # model replication: one broadcast of the packed DAG
+            dist.broadcast(rec, 0)
+            dist.broadcast(tab, 0)
+        scale = tree.geom()[8:10]
+        d_leaf = torch.empty(m_rank, dtype=torch.int32, device="cuda")
+
+        def step():
+            timed("bary_eval", lambda: ctx.bary_eval(nn, rec.data_ptr(), tab.data_ptr(), scale, d_y.data_ptr(), m_rank,
+                                                       2, d_s.data_ptr(), d_leaf.data_ptr()))
+        extra = {"dag_nodes": nn, "host_build_s": round(build_s, 3)}
+        dominant = "bary_eval"
+    else:
+        kind = pkg.RBF_GAUSSIAN if cfg["kind"] == "gaussian" else pkg.RBF_TPS
+        eps = 2.0 * n ** (1.0 / dim)
+        d_phi = torch.empty((n, n), dtype=f64, device="cuda") if rank == 0 else None
+        d_w = torch.empty(n, dtype=f64, device="cuda")
+        d_perm = torch.empty(n, dtype=torch.int32, device="cuda")
+
+        def step():
+            if rank == 0:
+                timed("fill", lambda: ctx.rbf_fill(kind, eps, d_x.data_ptr(), n, dim, dim, d_phi.data_ptr(), n))
+                d_w.copy_(d_f)
+                if kind == pkg.RBF_GAUSSIAN:
+                    def factor():
+                        st, info = ctx.cholesky_decomp1(n, d_phi.data_ptr(), n)
+                        assert st == 0, (st, info)
+                    timed("factor", factor)
+                    timed("solve", lambda: ctx.cholesky_svx(n, d_phi.data_ptr(), n, d_w.data_ptr()))
+                else:
+                    timed("factor", lambda: ctx.lu_decomp(n, d_phi.data_ptr(), n, d_perm.data_ptr()))
+
+                    def solve():
+                        assert ctx.lu_svx(n, d_phi.data_ptr(), n, d_perm.data_ptr(), d_w.data_ptr()) == 0
+                    timed("solve", solve)
+            if world > 1:
+                timed("bcast", lambda: dist.broadcast(d_w, 0))      # RCCL over xGMI: the only data-path collective
+            timed("eval", lambda: ctx.rbf_eval(kind, eps, d_x.data_ptr(), n, dim, dim, d_w.data_ptr(), d_y.data_ptr(),
+                                               m_rank, dim, d_s.data_ptr()))
+        extra = {"eps": eps}
+        dominant = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    phases.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=f64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ph_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in phases.items()}
+    ms_per_step = elapsed / args.steps * 1e3
+    value = m_total * args.steps / elapsed / 1e6
+
+    # ---- sanity of the result that was just produced (not timed)
+    sample = d_s[: min(m_rank, 4096)].cpu().numpy()
+    assert np.isfinite(sample).all(), "non-finite interpolated values"
+
+    if rank == 0:
+        out = {
+            "metric": "M interpolated points/sec (whole hot path: fill + solve + eval sweep per step)",
+            "value": round(value, 4), "unit": "M points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak" if cfg["shard"] == "per_gpu" else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["label"], "config": args.config, "n_centres": n, "dim": dim,
+                       "targets_per_gpu": m_rank, "targets_total": m_total,
+                       "parallelism": f"target shards x{world}, weights broadcast (RCCL)" if world > 1 else "1 GPU"},
+            "phase_ms": {k: round(v, 4) for k, v in ph_ms.items()},
+        }
+        out.update(rooflines(cfg, n, dim, m_rank, ph_ms, dominant))
+        out["extra"] = extra
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, n, dim)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def rooflines(cfg, n, dim, m_rank, ph, dominant):
+    """Roofline objects from live HIP-event timings.  Algorithmic work per SURVEY.md 8(d)."""
+    res = {}
+    if cfg["kind"] == "bary":
+        t = ph["bary_eval"] * 1e-3
+        by = 28.0 * m_rank                               # 16 B target in, 8 B value + 4 B leaf out
+        res["roofline"] = {"kernel": "bary_eval_kernel", "bound": "hbm", "achieved": round(by / t / 1e9, 3),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 6),
+                           "traffic": None,
+                           "note": "latency-bound DAG walk (~65 dependent 64-B gathers per target); "
+                                   "algorithmic bytes = 28 B/target"}
+        return res
+    flops = (n ** 3) / 3.0 if cfg["kind"] == "gaussian" else 2.0 * n ** 3 / 3.0
+    tf = ph["factor"] * 1e-3
+    te = ph["eval"] * 1e-3
+    by = (8.0 * dim + 8.0) * m_rank
+    r_factor = {"kernel": "factorisation (gemm_minus_kernel + panel kernels)", "bound": "mfma",
+                "achieved": round(flops / tf / 1e12, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / tf / 1e12 / FP64_PEAK_TFLOPS, 5), "traffic": None}
+    pair_ops = n * m_rank
+    r_eval = {"kernel": "rbf_eval_kernel", "bound": "hbm", "achieved": round(by / te / 1e9, 3), "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": round(by / te / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+              "pair_evals_per_s": round(pair_ops / te, 1),
+              "note": "compute-bound by construction (N pair-evals per 8d+8 B); see pair_evals_per_s vs fp64-VALU peak"}
+    res["roofline"] = r_factor if tf >= te else r_eval
+    res["roofline_other"] = r_eval if tf >= te else r_factor
+    res["solve_gflops"] = round(flops / tf / 1e9, 2)
+    res["eval_only_mpts"] = round(m_rank / te / 1e6, 3)
+    return res
+
+
+def cpu_baseline(cfg, n, dim):
+    """The CPU oracle (reference-order C restatement) timed on this box's host cores, one
+    thread, on a bounded sample of the same workload (kind: "port")."""
+    import oracle_lib as orc
+    cores = 1
+    if cfg["kind"] == "bary":
+        x = orc.synth_centres(n, 2)
+        f = orc.synth_response(x)
+        t = orc.Tree(2, n)
+        t0 = time.perf_counter()
+        assert t.init(x, flags=0, seed=0) == 0
+        build = time.perf_counter() - t0
+        ms = 200_000
+        y = orc.synth_targets(0, ms, 2)
+        t0 = time.perf_counter()
+        t.eval_many(x, f, y)
+        dt = time.perf_counter() - t0
+        return {"value": round(ms / dt / 1e6, 5), "unit": "M points/s", "cores": cores, "kind": "port",
+                "sample": f"first {ms} of the targets, N={n}; host DAG build {build:.2f} s (one-off, excluded)"}
+    kind = 0 if cfg["kind"] == "gaussian" else 1
+    eps = orc.gaussian_eps(n, dim)
+    x = orc.synth_centres(n, dim)
+    f = orc.synth_response(x)
+    # factorisation sample: N capped so the unblocked reference-order solver takes a few seconds
+    ns = min(n, 1536)
+    xs, fs = np.ascontiguousarray(x[:ns]), np.ascontiguousarray(f[:ns])
+    phi = orc.rbf_fill(kind, orc.gaussian_eps(ns, dim), xs)
+    t0 = time.perf_counter()
+    if kind == 0:
+        st, llt = orc.cholesky_decomp1(phi)
+        w = orc.cholesky_solve(llt, fs)
+    else:
+        lu, perm, _ = orc.lu_decomp(phi)
+        st, w = orc.lu_solve(lu, perm, fs)
+    dts = time.perf_counter() - t0
+    fl = (ns ** 3 / 3.0) if kind == 0 else (2.0 * ns ** 3 / 3.0)
+    # eval sample: ~10 s of single-core work at ~50 M pair-evals/s
+    ms = max(1000, int(5.0e8 // n))
+    y = orc.synth_targets(0, ms, dim)
+    wfull = np.resize(w, n)
+    t0 = time.perf_counter()
+    orc.rbf_eval(kind, eps, x, wfull, y)
+    dte = time.perf_counter() - t0
+    return {"value": round(ms / dte / 1e6, 6), "unit": "M points/s", "cores": cores, "kind": "port",
+            "sample": f"eval sweep of the first {ms} targets against all N={n} centres "
+                      f"({n * ms / dte / 1e6:.1f} M pair-evals/s); factor+solve at N={ns}: {dts:.2f} s",
+            "solve_gflops": round(fl / dts / 1e9, 3)}
+
+
+if __name__ == "__main__":
+    main()
