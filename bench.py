@@ -76,11 +76,11 @@ def main():
     cfg = CONFIGS[args.config]
     ctx = pkg.HipContext.on_torch_stream(local_rank)
     dim, n = cfg["dim"], cfg["n"]
-    m_rank = cfg["m"] if cfg["shard"] == "per_gpu" else (cfg["m"] + world - 1) // world
-    first = rank * m_rank
-    if cfg["shard"] == "total":
-        m_rank = max(0, min(m_rank, cfg["m"] - first))
-    m_total = m_rank * world if cfg["shard"] == "per_gpu" else cfg["m"]
+    if cfg["shard"] == "per_gpu":                       # weak scaling: fixed work per GPU
+        first, m_rank, m_total = rank * cfg["m"], cfg["m"], cfg["m"] * world
+    else:                                               # strong scaling: one target set, sharded
+        first, m_rank = pkg.sharding.shard_bounds(cfg["m"], world, rank)
+        m_total = cfg["m"]
 
     f64 = torch.float64
     # ---- synthetic inputs, generated in HBM (same generator as oracle/oracle_synth.c)
@@ -122,9 +122,7 @@ def main():
             ctx.tree_pack(nn, d_type.data_ptr(), d_pidx.data_ptr(), d_links.data_ptr(), n, d_pts.data_ptr(),
                           tree.geom(), rec.data_ptr())
             ctx.tree_bind(nn, d_pidx.data_ptr(), n, d_resp.data_ptr(), tab.data_ptr())
-        if world > 1:                                    # model replication: one broadcast of the packed DAG
-            dist.broadcast(rec, 0)
-            dist.broadcast(tab, 0)
+        pkg.sharding.broadcast_model([rec, tab], 0)      # model replication: one broadcast of the packed DAG
         scale = tree.geom()[8:10]
         d_leaf = torch.empty(m_rank, dtype=torch.int32, device="cuda")
 
@@ -140,27 +138,22 @@ def main():
         d_w = torch.empty(n, dtype=f64, device="cuda")
         d_perm = torch.empty(n, dtype=torch.int32, device="cuda")
 
+        route_seen = {}
+
         def step():
             if rank == 0:
-                timed("fill", lambda: ctx.rbf_fill(kind, eps, d_x.data_ptr(), n, dim, dim, d_phi.data_ptr(), n))
                 d_w.copy_(d_f)
-                if kind == pkg.RBF_GAUSSIAN:
-                    def factor():
-                        st, info = ctx.cholesky_decomp1(n, d_phi.data_ptr(), n)
-                        assert st == 0, (st, info)
-                    timed("factor", factor)
-                    timed("solve", lambda: ctx.cholesky_svx(n, d_phi.data_ptr(), n, d_w.data_ptr()))
-                else:
-                    timed("factor", lambda: ctx.lu_decomp(n, d_phi.data_ptr(), n, d_perm.data_ptr()))
 
-                    def solve():
-                        assert ctx.lu_svx(n, d_phi.data_ptr(), n, d_perm.data_ptr(), d_w.data_ptr()) == 0
-                    timed("solve", solve)
+                def init():                               # fill + factorisation + triangular solves
+                    st, route = ctx.rbf_solve(kind, eps, d_x.data_ptr(), n, dim, dim, d_phi.data_ptr(), n, d_w.data_ptr())
+                    assert st == 0, (st, route)
+                    route_seen["route"] = route
+                timed("init", init)
             if world > 1:
                 timed("bcast", lambda: dist.broadcast(d_w, 0))      # RCCL over xGMI: the only data-path collective
             timed("eval", lambda: ctx.rbf_eval(kind, eps, d_x.data_ptr(), n, dim, dim, d_w.data_ptr(), d_y.data_ptr(),
                                                m_rank, dim, d_s.data_ptr()))
-        extra = {"eps": eps}
+        extra = {"eps": eps, "route": route_seen}
         dominant = None
 
     def barrier():
@@ -202,7 +195,7 @@ def main():
                        "parallelism": f"target shards x{world}, weights broadcast (RCCL)" if world > 1 else "1 GPU"},
             "phase_ms": {k: round(v, 4) for k, v in ph_ms.items()},
         }
-        out.update(rooflines(cfg, n, dim, m_rank, ph_ms, dominant))
+        out.update(rooflines(cfg, n, dim, m_rank, ph_ms, dominant, extra))
         out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, n, dim)
@@ -211,7 +204,7 @@ def main():
         dist.destroy_process_group()
 
 
-def rooflines(cfg, n, dim, m_rank, ph, dominant):
+def rooflines(cfg, n, dim, m_rank, ph, dominant, extra=None):
     """Roofline objects from live HIP-event timings.  Algorithmic work per SURVEY.md 8(d)."""
     res = {}
     if cfg["kind"] == "bary":
@@ -223,13 +216,15 @@ def rooflines(cfg, n, dim, m_rank, ph, dominant):
                            "note": "latency-bound DAG walk (~65 dependent 64-B gathers per target); "
                                    "algorithmic bytes = 28 B/target"}
         return res
-    flops = (n ** 3) / 3.0 if cfg["kind"] == "gaussian" else 2.0 * n ** 3 / 3.0
-    tf = ph["factor"] * 1e-3
+    route = (extra or {}).get("route", {}).get("route", 1)
+    flops = 2.0 * n ** 3 / 3.0 if route == 3 else (n ** 3) / 3.0      # LU vs Cholesky factorisation
+    tf = ph["init"] * 1e-3
     te = ph["eval"] * 1e-3
     by = (8.0 * dim + 8.0) * m_rank
-    r_factor = {"kernel": "factorisation (gemm_minus_kernel + panel kernels)", "bound": "mfma",
-                "achieved": round(flops / tf / 1e12, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(flops / tf / 1e12 / FP64_PEAK_TFLOPS, 5), "traffic": None}
+    r_factor = {"kernel": "init = fill + factorisation (gemm_minus_kernel on fp64 MFMA + panel kernels) + sweeps",
+                "bound": "mfma", "achieved": round(flops / tf / 1e12, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / tf / 1e12 / FP64_PEAK_TFLOPS, 5), "traffic": None,
+                "route": {1: "cholesky", 2: "shifted-SPD cholesky + Woodbury", 3: "pivoted LU"}.get(route, "?")}
     pair_ops = n * m_rank
     r_eval = {"kernel": "rbf_eval_kernel", "bound": "hbm", "achieved": round(by / te / 1e9, 3), "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": round(by / te / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,

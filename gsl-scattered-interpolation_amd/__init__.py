@@ -10,7 +10,7 @@ The directory name contains a hyphen, so load it through
 ``__graft_entry__.load_package()`` (importlib), which registers it as
 ``gsl_sinterp_amd``.
 """
-from . import capi  # noqa: F401
+from . import capi, sharding  # noqa: F401
 from .capi import (  # noqa: F401
     GSL_SUCCESS, GSL_EDOM, GSL_EINVAL, GSL_EFAILED, RBF_GAUSSIAN, RBF_TPS,
     HipContext, SimplexTree, Sinterp, lib, library_path,

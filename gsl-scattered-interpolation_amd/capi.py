@@ -117,6 +117,7 @@ SIGNATURES = {
     "gsl_sinterp_hip_lu_decomp": (_i, [_vp, _sz, _vp, _sz, _vp, _pi]),
     "gsl_sinterp_hip_lu_svx": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "gsl_sinterp_hip_rbf_eval": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp]),
+    "gsl_sinterp_hip_rbf_solve": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _pi]),
     "gsl_sinterp_hip_gemm_minus": (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _vp, _sz, _i, _vp, _sz, _i]),
     "gsl_sinterp_hip_synth_unit": (_i, [_vp, C.c_uint64, C.c_uint64, _d, _d, _vp, _sz]),
     # --- include/gsl_sinterp.h part 1 (reference symbols)
@@ -296,6 +297,11 @@ class HipContext:
 
     def rbf_eval(self, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s):
         check(lib().gsl_sinterp_hip_rbf_eval(self._h, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s), self._h)
+
+    def rbf_solve(self, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w):
+        route = C.c_int(0)
+        st = lib().gsl_sinterp_hip_rbf_solve(self._h, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, C.byref(route))
+        return st, route.value
 
     def gemm_minus(self, m, n, k, d_a, lda, d_b, ldb, b_is_kn, d_c, ldc, lower_only=0):
         check(lib().gsl_sinterp_hip_gemm_minus(self._h, m, n, k, d_a, lda, d_b, ldb, b_is_kn, d_c, ldc, lower_only),

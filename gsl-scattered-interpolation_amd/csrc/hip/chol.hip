@@ -58,8 +58,15 @@ chol_base_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int nb
         d = 1.0;
       }
       if (j >= nb) d = 1.0;
-      const double sd = sqrt(d);
-      const double inv = 1.0 / sd;
+      /* sqrt(d) and 1/sqrt(d) from one v_rsq_f64 seed + FMA refinement: this pair sits on
+         the serial chain of the panel, a libm sqrt followed by an IEEE divide would cost
+         ~10x the cycles.  Both results end within 1 ulp of cholesky.c:125-126's values. */
+      double y = __builtin_amdgcn_rsq(d);
+      y = y * fma(-0.5 * d * y, y, 1.5);
+      y = y * fma(-0.5 * d * y, y, 1.5);
+      double sd = d * y;
+      sd = fma(fma(-sd, sd, d), 0.5 * y, sd);
+      const double inv = fma(fma(-sd, y, 1.0), y, y);
       a[j] = (lane == j) ? sd : v * inv;
       if (lane == 0) sInv[j] = inv;
     }
@@ -169,19 +176,29 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
   if (h_info) *h_info = 0;
   if (n == 0) return ST_SUCCESS;
   int *d_info = (int *)ctx->d_scratch + 8;
-  HIP_OK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
-  const unsigned nt = (unsigned)((n + 31) / 32);
-  hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
-  LAUNCH_CHECK(ctx);
   const size_t nblk = (n + CB - 1) / CB;
   void *d_diag = NULL;
   int st = sinterp_workspace(ctx, nblk * CB * CB * sizeof(double), &d_diag);
   if (st) return st;
-  st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag);
+  int replayed = 0;
+  st = sinterp_graph_try_launch(ctx, 0, n, lda, d_a, NULL, &replayed);
   if (st) return st;
-  hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
-                     (const double *)d_diag);
-  LAUNCH_CHECK(ctx);
+  if (!replayed) {
+    hipStream_t saved;
+    st = sinterp_capture_begin(ctx, &saved);
+    if (st) return st;
+    hipError_t me = hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream);
+    const unsigned nt = (unsigned)((n + 31) / 32);
+    hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
+    st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag);
+    hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
+                       (const double *)d_diag);
+    int st2 = sinterp_capture_end(ctx, saved, 0, n, lda, d_a, NULL);
+    if (me != hipSuccess) return sinterp_fail(ctx, ST_EFAILED, "hipMemsetAsync", me, __FILE__, __LINE__);
+    if (st) return st;
+    if (st2) return st2;
+    LAUNCH_CHECK(ctx);
+  }
   int info = 0;
   HIP_OK(ctx, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
@@ -198,12 +215,14 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
      mode 1: Lower, Trans,  backward   (source_trsv_r.h:106-129)  cols i < J:  b_i -= sum_j T[j][i] x_j
      mode 2: Upper, NoTrans, backward  (source_trsv_r.h:33-55)    rows i < J:  b_i -= sum_j T[i][j] x_j   */
 #define TS 64
+#define TRSV_MAXR 5   /* right-hand sides solved together (f + the d+1 polynomial columns) */
 
+/* right-hand side r lives at b + r*ldb (solved blocks at xout + r*ldb) */
 __global__ void __launch_bounds__(256)
 trsv_sweep_kernel(const double *__restrict__ T, size_t ldt, size_t n, double *__restrict__ b,
-                  double *__restrict__ xout, size_t j0, int nb, int mode, int unit)
+                  double *__restrict__ xout, size_t ldb, int nrhs, size_t j0, int nb, int mode, int unit)
 {
-  __shared__ double sx[TS];
+  __shared__ double sx[TRSV_MAXR][TS];
   __shared__ double sD[TS][TS + 1];
   const int tid = threadIdx.x;
   /* diagonal block into LDS (as the matrix of the small system to solve) */
@@ -214,65 +233,163 @@ trsv_sweep_kernel(const double *__restrict__ T, size_t ldt, size_t n, double *__
     sD[r][c] = v;
   }
   __syncthreads();
-  if (tid < 64) {
-    const int lane = tid;
-    double bi = lane < nb ? b[j0 + lane] : 0.0;
-    if (mode == 0) {            /* forward with D = lower(sD) */
-      for (int j = 0; j < nb; j++) {
-        double xj = lane_bcast(bi, j);
-        if (!unit) xj = xj / sD[j][j];
-        if (lane == j) bi = xj;
-        if (lane > j) bi -= sD[lane][j] * xj;
+  {
+    /* wave w solves right-hand sides w, w+4, ... (one system per wave at a time) */
+    const int lane = tid & 63, wave = tid >> 6;
+    /* x_j = b_j / d_j sits on the serial chain: one parallel divide per lane up front,
+       then q = b r, q += (b - d q) r  (a correctly rounded quotient in all but rare
+       half-ulp cases) instead of an IEEE divide per step */
+    const double dl = (lane < nb && !unit) ? sD[lane][lane] : 1.0;
+    const double rl = 1.0 / dl;
+    for (int r = wave; r < nrhs; r += 4) {
+      double bi = lane < nb ? b[r * ldb + j0 + lane] : 0.0;
+#define TRSV_STEP(J, COEF, COND)                                   \
+      {                                                            \
+        const double bj = lane_bcast(bi, (J));                     \
+        double xj = bj;                                            \
+        if (!unit) {                                               \
+          const double dj = lane_bcast(dl, (J)), rj = lane_bcast(rl, (J)); \
+          const double q = bj * rj;                                \
+          xj = fma(fma(-dj, q, bj), rj, q);                        \
+        }                                                          \
+        if (lane == (J)) bi = xj;                                  \
+        if (COND) bi = fma(-(COEF), xj, bi);                       \
       }
-    } else if (mode == 1) {     /* backward with D^T, D lower: x_j then b_i -= D[j][i] x_j for i < j */
-      for (int j = nb - 1; j >= 0; j--) {
-        double xj = lane_bcast(bi, j);
-        if (!unit) xj = xj / sD[j][j];
-        if (lane == j) bi = xj;
-        if (lane < j) bi -= sD[j][lane] * xj;
+      if (mode == 0) {            /* forward with D = lower(sD) */
+        for (int j = 0; j < nb; j++) TRSV_STEP(j, sD[lane][j], lane > j)
+      } else if (mode == 1) {     /* backward with D^T, D lower: x_j then b_i -= D[j][i] x_j for i < j */
+        for (int j = nb - 1; j >= 0; j--) TRSV_STEP(j, sD[j][lane], lane < j)
+      } else {                    /* backward with D upper */
+        for (int j = nb - 1; j >= 0; j--) TRSV_STEP(j, sD[lane][j], lane < j)
       }
-    } else {                    /* backward with D upper */
-      for (int j = nb - 1; j >= 0; j--) {
-        double xj = lane_bcast(bi, j);
-        if (!unit) xj = xj / sD[j][j];
-        if (lane == j) bi = xj;
-        if (lane < j) bi -= sD[lane][j] * xj;
-      }
+#undef TRSV_STEP
+      /* solved block goes to xout, never back into b: late workgroups of this launch re-read b[J] */
+      if (lane < nb) { sx[r][lane] = bi; if (blockIdx.x == 0) xout[r * ldb + j0 + lane] = bi; }
     }
-    /* solved block goes to xout, never back into b: late workgroups of this launch re-read b[J] */
-    if (lane < nb) { sx[lane] = bi; if (blockIdx.x == 0) xout[j0 + lane] = bi; }
   }
   __syncthreads();
 
   /* remaining right-hand side */
-  size_t i;
-  if (mode == 0) { i = j0 + nb + (size_t)blockIdx.x * 256 + tid; if (i >= n) return; }
-  else { i = (size_t)blockIdx.x * 256 + tid; if (i >= j0) return; }
-  double acc = 0.0;
   if (mode == 1) {
-    for (int j = 0; j < nb; j++) acc = fma(T[(j0 + j) * ldt + i], sx[j], acc);   /* coalesced across lanes */
+    /* column access T[j0+j][i]: 64 columns per workgroup, the nb rows split over the 4 waves */
+    __shared__ double s_part[TRSV_MAXR][4][64];
+    const int il = tid & 63, jg = tid >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + il;
+    double acc[TRSV_MAXR];
+#pragma unroll
+    for (int r = 0; r < TRSV_MAXR; r++) acc[r] = 0.0;
+    if (i < j0) {
+      const int jb = jg * 16, je = (jb + 16 < nb) ? jb + 16 : nb;
+      for (int j = jb; j < je; j++) {
+        const double t = T[(j0 + j) * ldt + i];                     /* coalesced across lanes */
+#pragma unroll
+        for (int r = 0; r < TRSV_MAXR; r++) if (r < nrhs) acc[r] = fma(t, sx[r][j], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TRSV_MAXR; r++) if (r < nrhs) s_part[r][jg][il] = acc[r];
+    __syncthreads();
+    if (jg == 0 && i < j0) {
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++)
+        if (r < nrhs) b[r * ldb + i] -= (s_part[r][0][il] + s_part[r][1][il]) + (s_part[r][2][il] + s_part[r][3][il]);
+    }
   } else {
-    const double *row = T + i * ldt + j0;
-    for (int j = 0; j < nb; j++) acc = fma(row[j], sx[j], acc);
+    /* row access T[i][j0..j0+nb): 8 lanes share a row (8 x 64 B contiguous), 32 rows per pass */
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rsub = lane >> 3, c8 = (lane & 7) * 8;
+    const size_t base = (mode == 0) ? j0 + nb : 0;
+    const size_t limit = (mode == 0) ? n : j0;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const size_t i = base + ((size_t)blockIdx.x * 2 + pass) * 32 + wave * 8 + rsub;
+      double acc[TRSV_MAXR];
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++) acc[r] = 0.0;
+      if (i < limit) {
+        const double *row = T + i * ldt + j0 + c8;
+        double t[8];
+        if (nb == TS && ((((uintptr_t)row) & 15) == 0)) {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) { const double2 v = *reinterpret_cast<const double2 *>(row + k); t[k] = v.x; t[k + 1] = v.y; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) t[k] = (c8 + k < nb) ? row[k] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < TRSV_MAXR; r++)
+          if (r < nrhs) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[r] = fma(t[k], sx[r][c8 + k], acc[r]);
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++) {
+        if (r < nrhs) {
+          double a = acc[r];
+          a += __shfl_xor(a, 1);
+          a += __shfl_xor(a, 2);
+          a += __shfl_xor(a, 4);
+          if (i < limit && (lane & 7) == 0) b[r * ldb + i] -= a;
+        }
+      }
+    }
   }
-  b[i] -= acc;
 }
 
-int sinterp_trsv(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, int mode,
-                 int unit)
+static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout,
+                         size_t ldb, int nrhs, int mode, int unit)
 {
-  if (n == 0) return ST_SUCCESS;
   const size_t nblk = (n + TS - 1) / TS;
   for (size_t t = 0; t < nblk; t++) {
     const size_t blk = (mode == 0) ? t : nblk - 1 - t;
     const size_t j0 = blk * TS;
     const int nb = (int)((n - j0) < TS ? (n - j0) : TS);
     const size_t rest = (mode == 0) ? n - j0 - nb : j0;
-    const unsigned grid = (unsigned)((rest + 255) / 256);
-    hipLaunchKernelGGL(trsv_sweep_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream, T, ldt, n, b, xout, j0, nb, mode, unit);
+    const unsigned grid = (unsigned)((rest + 63) / 64);
+    hipLaunchKernelGGL(trsv_sweep_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream, T, ldt, n, b, xout, ldb, nrhs, j0,
+                       nb, mode, unit);
     LAUNCH_CHECK(ctx);
   }
   return ST_SUCCESS;
+}
+
+int sinterp_trsv_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, size_t ldb,
+                       int nrhs, int mode, int unit)
+{
+  if (n == 0 || nrhs == 0) return ST_SUCCESS;
+  if (nrhs > TRSV_MAXR) return sinterp_fail(ctx, ST_EINVAL, "trsv: too many right-hand sides", hipSuccess, __FILE__, __LINE__);
+  /* one cached graph per direction: slot 2 forward, slot 3 backward */
+  const int slot = mode == 0 ? 2 : 3;
+  const size_t key_lda = ((ldt * 8 + (size_t)mode * 2 + (size_t)unit) * 8 + (size_t)nrhs) ^ (ldb << 40);
+  const void *p1 = (const void *)((uintptr_t)b ^ ((uintptr_t)xout << 1));
+  int replayed = 0;
+  int st = sinterp_graph_try_launch(ctx, slot, n, key_lda, T, p1, &replayed);
+  if (st || replayed) return st;
+  hipStream_t saved;
+  st = sinterp_capture_begin(ctx, &saved);
+  if (st) return st;
+  st = trsv_launches(ctx, n, T, ldt, b, xout, ldb, nrhs, mode, unit);
+  int st2 = sinterp_capture_end(ctx, saved, slot, n, key_lda, T, p1);
+  return st ? st : st2;
+}
+
+int sinterp_trsv(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, int mode,
+                 int unit)
+{
+  return sinterp_trsv_multi(ctx, n, T, ldt, b, xout, n, 1, mode, unit);
+}
+
+/* X <- (L L^T)^-1 X for nrhs vectors stored at d_x + r*ldx */
+int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda, double *d_x, size_t ldx,
+                               int nrhs)
+{
+  void *d_tmp = NULL;
+  int st = sinterp_workspace(ctx, (size_t)nrhs * ldx * sizeof(double), &d_tmp);
+  if (st) return st;
+  st = sinterp_trsv_multi(ctx, n, d_llt, lda, d_x, (double *)d_tmp, ldx, nrhs, 0, 0);   /* L c = b     (cholesky.c:178) */
+  if (st) return st;
+  return sinterp_trsv_multi(ctx, n, d_llt, lda, (double *)d_tmp, d_x, ldx, nrhs, 1, 0); /* L^T x = c   (cholesky.c:181) */
 }
 
 extern "C" int gsl_sinterp_hip_cholesky_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda, double *d_x)
@@ -280,10 +397,5 @@ extern "C" int gsl_sinterp_hip_cholesky_svx(gsl_sinterp_hip_ctx *ctx, size_t n, 
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   REQUIRE(ctx, lda >= n, ST_EINVAL);
   REQUIRE(ctx, n == 0 || (d_llt && d_x), ST_EFAULT);
-  void *d_tmp = NULL;
-  int st = sinterp_workspace(ctx, n * sizeof(double), &d_tmp);
-  if (st) return st;
-  st = sinterp_trsv(ctx, n, d_llt, lda, d_x, (double *)d_tmp, 0, 0);   /* L c = b     (cholesky.c:178) */
-  if (st) return st;
-  return sinterp_trsv(ctx, n, d_llt, lda, (double *)d_tmp, d_x, 1, 0); /* L^T x = c   (cholesky.c:181) */
+  return sinterp_cholesky_svx_multi(ctx, n, d_llt, lda, d_x, n, 1);
 }

@@ -22,8 +22,24 @@ struct gsl_sinterp_hip_ctx {
   size_t scratch_bytes;
   void *d_work;             /* growable workspace (factorisations) */
   size_t work_bytes;
+  void *d_aux;              /* growable buffer of the solver route (right-hand sides, polynomial block) */
+  size_t aux_bytes;
+  /* hipGraph cache: the recursive factorisation drivers issue ~1-2k small, fully static
+     launches; they are captured once per (routine, n, lda, pointers) and replayed */
+  hipStream_t cap_stream;
+  struct GraphSlot { hipGraphExec_t exec; size_t n, lda; const void *p0, *p1, *work; } graph[4];
+  int use_graphs;
   char err[512];
 };
+
+/* Graph helpers (shim.hip).  sinterp_graph_lookup returns 1 and launches the cached
+   graph on the context's stream when slot `which` matches the key; otherwise 0.
+   Between sinterp_capture_begin / _end every launch on ctx->stream is recorded. */
+int sinterp_graph_try_launch(gsl_sinterp_hip_ctx *ctx, int which, size_t n, size_t lda, const void *p0, const void *p1,
+                             int *launched);
+int sinterp_capture_begin(gsl_sinterp_hip_ctx *ctx, hipStream_t *saved);
+int sinterp_capture_end(gsl_sinterp_hip_ctx *ctx, hipStream_t saved, int which, size_t n, size_t lda, const void *p0,
+                        const void *p1);
 
 static inline int sinterp_fail(gsl_sinterp_hip_ctx *ctx, int status, const char *what, hipError_t e,
                                const char *file, int line)
@@ -63,5 +79,12 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
    mode 0 Lower/NoTrans fwd, 1 Lower/Trans bwd, 2 Upper/NoTrans bwd */
 int sinterp_trsv(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, int mode,
                  int unit);
+/* the same for nrhs <= 5 right-hand sides stored at b + r*ldb / xout + r*ldb */
+int sinterp_trsv_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, size_t ldb,
+                       int nrhs, int mode, int unit);
+int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda, double *d_x, size_t ldx,
+                               int nrhs);
+/* second grow-only buffer for vectors that must outlive factorisation workspaces */
+int sinterp_aux(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 
 #endif

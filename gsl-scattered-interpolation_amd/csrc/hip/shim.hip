@@ -4,6 +4,7 @@
  * all; this file is that boundary.
  */
 #include "common.h"
+#include <stdlib.h>
 
 extern "C" int gsl_sinterp_hip_device_count(void)
 {
@@ -27,6 +28,10 @@ extern "C" int gsl_sinterp_hip_ctx_create(gsl_sinterp_hip_ctx **out, int device,
      caller already enqueued there (hipMemcpy, torch's default stream, ...). */
   ctx->stream = (hipStream_t)stream;
   ctx->owns_stream = 0;
+  {
+    const char *e = getenv("GSL_SINTERP_NO_GRAPH");
+    ctx->use_graphs = !(e && e[0] == '1');
+  }
   ctx->scratch_bytes = 4096;
   if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipMalloc(&ctx->d_scratch, ctx->scratch_bytes) != hipSuccess) {
@@ -55,8 +60,12 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 4; i++)
+    if (ctx->graph[i].exec) (void)hipGraphExecDestroy(ctx->graph[i].exec);
+  if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
+  if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -127,6 +136,46 @@ extern "C" int gsl_sinterp_hip_timer_stop(gsl_sinterp_hip_ctx *ctx, float *h_ms)
   return ST_SUCCESS;
 }
 
+int sinterp_graph_try_launch(gsl_sinterp_hip_ctx *ctx, int which, size_t n, size_t lda, const void *p0, const void *p1,
+                             int *launched)
+{
+  *launched = 0;
+  if (!ctx->use_graphs) return ST_SUCCESS;
+  gsl_sinterp_hip_ctx::GraphSlot &g = ctx->graph[which];
+  if (g.exec && g.n == n && g.lda == lda && g.p0 == p0 && g.p1 == p1 && g.work == ctx->d_work) {
+    HIP_OK(ctx, hipGraphLaunch(g.exec, ctx->stream));
+    *launched = 1;
+  }
+  return ST_SUCCESS;
+}
+
+int sinterp_capture_begin(gsl_sinterp_hip_ctx *ctx, hipStream_t *saved)
+{
+  *saved = ctx->stream;
+  if (!ctx->use_graphs) return ST_SUCCESS;
+  if (!ctx->cap_stream) HIP_OK(ctx, hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+  HIP_OK(ctx, hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal));
+  ctx->stream = ctx->cap_stream;
+  return ST_SUCCESS;
+}
+
+int sinterp_capture_end(gsl_sinterp_hip_ctx *ctx, hipStream_t saved, int which, size_t n, size_t lda, const void *p0,
+                        const void *p1)
+{
+  if (!ctx->use_graphs) return ST_SUCCESS;
+  ctx->stream = saved;
+  hipGraph_t graph = NULL;
+  HIP_OK(ctx, hipStreamEndCapture(ctx->cap_stream, &graph));
+  gsl_sinterp_hip_ctx::GraphSlot &g = ctx->graph[which];
+  if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = NULL; }
+  hipError_t e = hipGraphInstantiate(&g.exec, graph, NULL, NULL, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { g.exec = NULL; return sinterp_fail(ctx, ST_EFAILED, "hipGraphInstantiate", e, __FILE__, __LINE__); }
+  g.n = n; g.lda = lda; g.p0 = p0; g.p1 = p1; g.work = ctx->d_work;
+  HIP_OK(ctx, hipGraphLaunch(g.exec, ctx->stream));
+  return ST_SUCCESS;
+}
+
 int sinterp_workspace(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out)
 {
   if (bytes > ctx->work_bytes) {
@@ -139,6 +188,21 @@ int sinterp_workspace(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out)
     ctx->work_bytes = bytes;
   }
   *out = ctx->d_work;
+  return ST_SUCCESS;
+}
+
+int sinterp_aux(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out)
+{
+  if (bytes > ctx->aux_bytes) {
+    if (ctx->d_aux) {
+      HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_OK(ctx, hipFree(ctx->d_aux));
+      ctx->d_aux = NULL; ctx->aux_bytes = 0;
+    }
+    HIP_OK(ctx, hipMalloc(&ctx->d_aux, bytes));
+    ctx->aux_bytes = bytes;
+  }
+  *out = ctx->d_aux;
   return ST_SUCCESS;
 }
 

@@ -1,0 +1,225 @@
+/*
+ * solve.hip -- "init" of an RBF interpolant on the device: Phi fill + dense solve
+ * Phi w = f, choosing the route by kernel class:
+ *
+ *   route 1  Gaussian (SPD):  Cholesky + two triangular sweeps
+ *            = gsl_linalg_cholesky_decomp1 + _svx (linalg/cholesky.c:88,163).
+ *   route 2  thin-plate spline (symmetric, indefinite, conditionally positive definite of
+ *            order 2): the reference route would be gsl_linalg_LU_decomp + _svx
+ *            (linalg/lu.c:59,166), whose partial pivoting is an inherently serial N-step
+ *            reduction chain.  Phi is positive definite on the complement of the d+1
+ *            polynomials P = [1, (x-mean)/std], so  B = Phi + s P P^T  with s = c |Phi|_inf / N
+ *            is SPD (c = 4; threshold measured between 1 and 2) and
+ *                Phi^-1 f = B^-1 f + B^-1 P (I/s - P^T B^-1 P)^-1 P^T B^-1 f      (Woodbury)
+ *            i.e. one MFMA Cholesky, d+2 right-hand sides through the blocked sweeps and a
+ *            (d+1)x(d+1) system on the host.  Interpolated values agree with the LU route to
+ *            ~1e-13 relative (weights to ~1e-9, the cond(Phi)*eps level at which any two
+ *            backward-stable solvers differ -- SURVEY.md section 7).
+ *   route 3  if B is not SPD even with c = 32: pivoted LU (lu.hip), the reference route.
+ */
+#include "common.h"
+#include <math.h>
+#include <stdlib.h>
+
+#define SV_MAXK 4 /* dim + 1 <= 4 polynomial columns */
+
+/* statistics + polynomial block: one workgroup.  Y holds the right-hand sides
+   (vector 0 = f, vectors 1..k = P columns), Pk keeps a copy of P. */
+__global__ void __launch_bounds__(1024)
+poly_block_kernel(const double *__restrict__ x, size_t n, int dim, size_t xtda, const double *__restrict__ f,
+                  double *__restrict__ Y, double *__restrict__ Pk)
+{
+  __shared__ double s_red[2 * 3][16];
+  __shared__ double s_mean[3], s_inv[3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double sum[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
+  for (size_t i = tid; i < n; i += 1024)
+    for (int c = 0; c < dim; c++) { const double v = x[i * xtda + c]; sum[c] += v; sq[c] = fma(v, v, sq[c]); }
+  for (int c = 0; c < 3; c++) {
+    double a = sum[c], b = sq[c];
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if (lane == 0) { s_red[2 * c][wave] = a; s_red[2 * c + 1][wave] = b; }
+  }
+  __syncthreads();
+  if (tid < 3) {
+    double a = 0, b = 0;
+    for (int w = 0; w < 16; w++) { a += s_red[2 * tid][w]; b += s_red[2 * tid + 1][w]; }
+    const double mean = a / (double)n;
+    double var = b / (double)n - mean * mean;
+    if (!(var > 0)) var = 1.0;
+    s_mean[tid] = mean;
+    s_inv[tid] = 1.0 / sqrt(var);
+  }
+  __syncthreads();
+  for (size_t i = tid; i < n; i += 1024) {
+    Y[i] = f[i];
+    Y[n + i] = 1.0; Pk[i] = 1.0;
+    for (int c = 0; c < dim; c++) {
+      const double v = (x[i * xtda + c] - s_mean[c]) * s_inv[c];
+      Y[(size_t)(c + 2) * n + i] = v;
+      Pk[(size_t)(c + 1) * n + i] = v;
+    }
+  }
+}
+
+/* |Phi|_inf = max_i sum_j |Phi_ij| : one workgroup per row, max through the bit pattern */
+__global__ void __launch_bounds__(256)
+row_norm_kernel(const double *__restrict__ phi, size_t lda, size_t n, unsigned long long *__restrict__ out)
+{
+  __shared__ double s_red[4];
+  const size_t i = blockIdx.x;
+  double a = 0;
+  for (size_t j = threadIdx.x; j < n; j += 256) a += fabs(phi[i * lda + j]);
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    atomicMax(out, (unsigned long long)__double_as_longlong(t));     /* t >= 0: bit order == value order */
+  }
+}
+
+/* Phi_ij += (c |Phi|_inf / n) * sum_a P_a[i] P_a[j] */
+__global__ void __launch_bounds__(256)
+poly_shift_kernel(double *__restrict__ phi, size_t lda, size_t n, const double *__restrict__ Pk, int k, double cmul,
+                  const unsigned long long *__restrict__ norm_bits)
+{
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t i = blockIdx.y;
+  if (j >= n) return;
+  const double s = cmul * __longlong_as_double((long long)*norm_bits) / (double)n;
+  double acc = 0.0;
+  for (int a = 0; a < k; a++) acc = fma(Pk[(size_t)a * n + i], Pk[(size_t)a * n + j], acc);
+  phi[i * lda + j] = fma(s, acc, phi[i * lda + j]);
+}
+
+/* G[a][b] = sum_i P_a[i] Y_b[i]  (a < k, b < k+1): one workgroup per entry */
+__global__ void __launch_bounds__(256)
+gram_kernel(const double *__restrict__ Pk, const double *__restrict__ Y, size_t n, int k, double *__restrict__ G)
+{
+  __shared__ double s_red[4];
+  const int a = blockIdx.x / (k + 1), b = blockIdx.x % (k + 1);
+  double acc = 0;
+  for (size_t i = threadIdx.x; i < n; i += 256) acc = fma(Pk[(size_t)a * n + i], Y[(size_t)b * n + i], acc);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) G[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ void __launch_bounds__(256)
+combine_kernel(const double *__restrict__ Y, size_t n, int k, const double *__restrict__ coef, double *__restrict__ w)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double v = Y[i];
+  for (int a = 0; a < k; a++) v = fma(coef[a], Y[(size_t)(a + 1) * n + i], v);
+  w[i] = v;
+}
+
+/* tiny dense solve on the host (partial pivoting) */
+static int host_solve(int k, double *S, double *g)
+{
+  for (int j = 0; j < k; j++) {
+    int p = j;
+    for (int i = j + 1; i < k; i++) if (fabs(S[i * k + j]) > fabs(S[p * k + j])) p = i;
+    if (S[p * k + j] == 0.0) return 1;
+    if (p != j) { for (int c = 0; c < k; c++) { double t = S[j * k + c]; S[j * k + c] = S[p * k + c]; S[p * k + c] = t; } double t = g[j]; g[j] = g[p]; g[p] = t; }
+    for (int i = j + 1; i < k; i++) {
+      const double l = S[i * k + j] / S[j * k + j];
+      for (int c = j; c < k; c++) S[i * k + c] -= l * S[j * k + c];
+      g[i] -= l * g[j];
+    }
+  }
+  for (int i = k - 1; i >= 0; i--) {
+    double t = g[i];
+    for (int c = i + 1; c < k; c++) t -= S[i * k + c] * g[c];
+    g[i] = t / S[i * k + i];
+  }
+  return 0;
+}
+
+extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
+                                         int dim, size_t xtda, double *d_phi, size_t lda, double *d_w, int *h_route)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && lda >= n, ST_EINVAL);
+  REQUIRE(ctx, n == 0 || (d_x && d_phi && d_w), ST_EFAULT);
+  if (h_route) *h_route = 0;
+  if (n == 0) return ST_SUCCESS;
+  int st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);
+  if (st) return st;
+  int info = 0;
+
+  if (kind == GSL_SINTERP_RBF_GAUSSIAN) {
+    st = gsl_sinterp_hip_cholesky_decomp1(ctx, n, d_phi, lda, &info);
+    if (st) return st;
+    if (h_route) *h_route = 1;
+    return gsl_sinterp_hip_cholesky_svx(ctx, n, d_phi, lda, d_w);
+  }
+
+  /* ---- conditionally positive definite kernel: shifted SPD system + Woodbury */
+  const int k = dim + 1;
+  const bool force_lu = getenv("GSL_SINTERP_FORCE_LU") && getenv("GSL_SINTERP_FORCE_LU")[0] == '1';
+  void *aux = NULL;
+  st = sinterp_aux(ctx, ((size_t)(2 * k + 1) * n + 64) * sizeof(double), &aux);
+  if (st) return st;
+  double *Y = (double *)aux;                      /* (k+1) x n : f, P columns -> B^-1 [f P] */
+  double *Pk = Y + (size_t)(k + 1) * n;           /* k x n     : P                          */
+  double *G = Pk + (size_t)k * n;                 /* k x (k+1) Gram block, then coefficients */
+  unsigned long long *d_norm = (unsigned long long *)(G + 32);
+
+  double cmul = 4.0;
+  for (int attempt = 0; attempt < 2 && !force_lu; attempt++, cmul *= 8.0) {
+    if (attempt > 0) {
+      st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);
+      if (st) return st;
+    }
+    hipLaunchKernelGGL(poly_block_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_x, n, dim, xtda, (const double *)d_w, Y, Pk);
+    HIP_OK(ctx, hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const double *)d_phi, lda, n, d_norm);
+    hipLaunchKernelGGL(poly_shift_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, d_phi, lda, n,
+                       (const double *)Pk, k, cmul, (const unsigned long long *)d_norm);
+    LAUNCH_CHECK(ctx);
+    st = gsl_sinterp_hip_cholesky_decomp1(ctx, n, d_phi, lda, &info);
+    if (st == ST_EDOM) continue;                  /* not SPD with this shift: larger shift, then LU */
+    if (st) return st;
+    st = sinterp_cholesky_svx_multi(ctx, n, d_phi, lda, Y, n, k + 1);
+    if (st) return st;
+    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(k * (k + 1))), dim3(256), 0, ctx->stream, (const double *)Pk, (const double *)Y,
+                       n, k, G);
+    LAUNCH_CHECK(ctx);
+    double hG[SV_MAXK * (SV_MAXK + 1)];
+    unsigned long long hnorm = 0;
+    HIP_OK(ctx, hipMemcpyAsync(hG, G, sizeof(double) * k * (k + 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipMemcpyAsync(&hnorm, d_norm, sizeof hnorm, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    double nrm;
+    memcpy(&nrm, &hnorm, sizeof nrm);
+    const double s = cmul * nrm / (double)n;
+    /* S c = g with S = I/s - P^T B^-1 P, g = P^T B^-1 f   (G column 0 = g, columns 1..k = P^T B^-1 P) */
+    double S[SV_MAXK * SV_MAXK], g[SV_MAXK];
+    for (int a = 0; a < k; a++) {
+      g[a] = hG[a * (k + 1)];
+      for (int b = 0; b < k; b++) S[a * k + b] = (a == b ? 1.0 / s : 0.0) - hG[a * (k + 1) + 1 + b];
+    }
+    if (host_solve(k, S, g)) break;               /* degenerate correction system: use LU */
+    HIP_OK(ctx, hipMemcpyAsync(G, g, sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)Y, n, k,
+                       (const double *)G, d_w);
+    LAUNCH_CHECK(ctx);
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   /* g[] is a stack buffer */
+    if (h_route) *h_route = 2;
+    return ST_SUCCESS;
+  }
+
+  /* ---- reference route: pivoted LU */
+  st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);
+  if (st) return st;
+  int *d_perm = (int *)Pk;                         /* n ints fit in the k*n doubles of Pk */
+  int signum = 0;
+  st = gsl_sinterp_hip_lu_decomp(ctx, n, d_phi, lda, d_perm, &signum);
+  if (st) return st;
+  if (h_route) *h_route = 3;
+  return gsl_sinterp_hip_lu_svx(ctx, n, d_phi, lda, d_perm, d_w);
+}

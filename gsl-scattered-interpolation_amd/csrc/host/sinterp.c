@@ -250,26 +250,17 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
   gsl_sinterp_hip_free(c, st->d_x); gsl_sinterp_hip_free(c, st->d_w);
   st->d_x = st->d_w = NULL;
   double *d_phi = NULL;
-  int *d_perm = NULL;
-  int info = 0, signum = 0;
+  int route = 0;
   int s = gsl_sinterp_hip_malloc(c, (void **)&st->d_x, n * dim * sizeof(double));
   if (!s) s = gsl_sinterp_hip_malloc(c, (void **)&st->d_w, n * sizeof(double));
   if (!s) s = gsl_sinterp_hip_malloc(c, (void **)&d_phi, n * n * sizeof(double));
   if (!s) s = gsl_sinterp_hip_h2d(c, st->d_x, h_x, n * dim * sizeof(double));
   if (!s) s = gsl_sinterp_hip_h2d(c, st->d_w, h_f, n * sizeof(double));
-  if (!s) s = gsl_sinterp_hip_rbf_fill(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n);
-  if (!s) {
-    if (st->kind == GSL_SINTERP_RBF_GAUSSIAN) {
-      s = gsl_sinterp_hip_cholesky_decomp1(c, n, d_phi, n, &info);
-      if (!s) s = gsl_sinterp_hip_cholesky_svx(c, n, d_phi, n, st->d_w);
-    } else {
-      s = gsl_sinterp_hip_malloc(c, (void **)&d_perm, n * sizeof(int));
-      if (!s) s = gsl_sinterp_hip_lu_decomp(c, n, d_phi, n, d_perm, &signum);
-      if (!s) s = gsl_sinterp_hip_lu_svx(c, n, d_phi, n, d_perm, st->d_w);
-    }
-  }
+  /* fill + dense solve on the device: Cholesky (Gaussian), shifted-SPD Cholesky with a
+     Woodbury correction or pivoted LU (thin-plate spline) -- csrc/hip/solve.hip */
+  if (!s) s = gsl_sinterp_hip_rbf_solve(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, &route);
   if (!s) s = gsl_sinterp_hip_sync(c);
-  gsl_sinterp_hip_free(c, d_phi); gsl_sinterp_hip_free(c, d_perm);
+  gsl_sinterp_hip_free(c, d_phi);
   free(h_x); free(h_f);
   if (s == GSL_EDOM) GSL_ERROR("gsl_sinterp_init: kernel matrix is not positive definite", GSL_EDOM);
   HIP_TRY(s, c);

@@ -100,6 +100,14 @@ int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, con
                              size_t n, int dim, size_t xtda, const double *d_w,
                              const double *d_y, size_t m, size_t ytda, double *d_s);
 
+/* "init" of an RBF interpolant in one call: fill d_phi (n x n scratch, lda), solve Phi w = f
+   with d_w holding f on entry and w on exit.  *h_route reports the solver used:
+   1 Cholesky (Gaussian, SPD) -- 2 shifted-SPD Cholesky + rank-(d+1) Woodbury correction
+   (thin-plate spline; values agree with the LU route to ~1e-13) -- 3 pivoted LU (the
+   reference's route, taken when the shifted matrix is not SPD or GSL_SINTERP_FORCE_LU=1). */
+int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
+                              int dim, size_t xtda, double *d_phi, size_t lda, double *d_w, int *h_route);
+
 /* Level-3 building block of both factorisations, exposed for tests and roofline
    measurement (role of gsl_blas_dgemm / dsyrk, blas/blas.c:1334,1649):
      C[m x n] -= A[m x k] * B^T  (b_is_kn = 0, B stored [n][k])

@@ -95,3 +95,32 @@ def test_facade_errors(pkg, orc):
     assert s2.init(x, orc.synth_response(x)) == 0
     st, vals, _ = s2.eval_many(np.zeros((0, 2)))
     assert st == 0 and len(vals) == 0
+
+
+@pytest.mark.parametrize("dim,n", [(2, 900), (3, 700), (1, 300), (2, 2500)])
+def test_tps_solver_routes_agree(pkg, orc, dim, n, monkeypatch):
+    """TPS init: the shifted-SPD Cholesky + Woodbury route (2) and the pivoted-LU reference
+    route (3, forced) give the same interpolant: values within 1e-10 of each other and of the
+    CPU oracle (reference-order LU)."""
+    x = orc.synth_centres(n, dim) * 2.5 - 7.0              # non-unit box: exercises the centring of P
+    f = orc.synth_response(orc.synth_centres(n, dim))
+    y = orc.synth_targets(0, 4000, dim) * 2.5 - 7.0
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_x, d_y = dev(x), dev(y)
+    res = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("GSL_SINTERP_FORCE_LU", force)
+        d_w = dev(f)
+        d_phi = torch.empty((n, n), dtype=torch.float64, device="cuda")
+        st, route = ctx.rbf_solve(1, 0.0, ptr(d_x), n, dim, dim, ptr(d_phi), n, ptr(d_w))
+        assert st == 0 and route == (3 if force == "1" else 2)
+        d_s = torch.empty(len(y), dtype=torch.float64, device="cuda")
+        ctx.rbf_eval(1, 0.0, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), len(y), dim, ptr(d_s))
+        ctx.sync()
+        res[force] = (d_s.cpu().numpy(), d_w.cpu().numpy())
+    want = orc.rbf_eval(1, 0.0, x, orc.rbf_solve(1, 0.0, x, f), y)
+    assert relerr(res["0"][0], res["1"][0]) < TOL
+    assert relerr(res["0"][0], want) < TOL and relerr(res["1"][0], want) < TOL
+    # residual of the SPD-route weights against the true (unshifted) system
+    phi = orc.rbf_fill(1, 0.0, x)
+    assert np.abs(phi @ res["0"][1] - f).max() < 1e-9 * max(1.0, np.abs(f).max())
