@@ -38,6 +38,7 @@ struct GemmArgs {
   double *C; size_t ldc;
   int lower_only;
   int tiles_m, tiles_n;
+  unsigned n_active;   /* tiles that are launched: all, or the lower trapezoid when lower_only */
 };
 
 __device__ __forceinline__ double2 ld2(const double *p, bool ok0, bool ok1, bool vec)
@@ -49,7 +50,7 @@ __device__ __forceinline__ double2 ld2(const double *p, bool ok0, bool ok1, bool
   return v;
 }
 
-template <int B_IS_KN>
+template <int B_IS_KN, bool FULL>
 __global__ void __launch_bounds__(256, 2)
 gemm_minus_kernel(GemmArgs g)
 {
@@ -61,8 +62,23 @@ gemm_minus_kernel(GemmArgs g)
   const unsigned nwg = gridDim.x, bid = blockIdx.x;
   const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8;
   const unsigned tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  const int tm = (int)(tile / g.tiles_n), tn = (int)(tile % g.tiles_n);
-  if (g.lower_only && tn > tm) return;
+  int tm, tn;
+  if (!g.lower_only) {
+    tm = (int)(tile / g.tiles_n); tn = (int)(tile % g.tiles_n);
+  } else {
+    /* only the lower trapezoid is launched (row tm holds min(tm+1, tiles_n) tiles), so every XCD
+       gets the same number of equally heavy tiles; consecutive ids share the A row panel */
+    const unsigned tri = (unsigned)g.tiles_n * (unsigned)(g.tiles_n + 1) / 2;
+    if (tile < tri) {
+      tm = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+      while ((unsigned)(tm + 1) * (unsigned)(tm + 2) / 2 <= tile) tm++;
+      while ((unsigned)tm * (unsigned)(tm + 1) / 2 > tile) tm--;
+      tn = (int)(tile - (unsigned)tm * (unsigned)(tm + 1) / 2);
+    } else {
+      const unsigned t2 = tile - tri;
+      tm = g.tiles_n + (int)(t2 / g.tiles_n); tn = (int)(t2 % g.tiles_n);
+    }
+  }
 
   const size_t row0 = (size_t)tm * GT_BM, col0 = (size_t)tn * GT_BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,6 +100,15 @@ gemm_minus_kernel(GemmArgs g)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int c = tid + 256 * i;
+      if (FULL) {   /* whole tiles, 16-byte aligned operands: no predicates */
+        { const int rr = c >> 3, kc = (c & 7) * 2;
+          ra[i] = *reinterpret_cast<const double2 *>(g.A + (row0 + rr) * g.lda + k0 + kc); }
+        if (B_IS_KN) { const int kk = c >> 6, nc = (c & 63) * 2;
+          rb[i] = *reinterpret_cast<const double2 *>(g.B + (k0 + kk) * g.ldb + col0 + nc); }
+        else { const int rr = c >> 3, kc = (c & 7) * 2;
+          rb[i] = *reinterpret_cast<const double2 *>(g.B + (col0 + rr) * g.ldb + k0 + kc); }
+        continue;
+      }
       { /* A: 128 rows x 8 chunks of 2 */
         const int rr = c >> 3, kc = (c & 7) * 2;
         const size_t grow = row0 + rr, gk = k0 + kc;
@@ -152,7 +177,7 @@ gemm_minus_kernel(GemmArgs g)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const size_t grow = row0 + wr * 64 + i * 16 + fq + 4 * rg;
-        if (grow < g.m && gcol < g.n && (!g.lower_only || gcol <= grow)) {
+        if ((FULL || (grow < g.m && gcol < g.n)) && (!g.lower_only || gcol <= grow)) {
           double *p = g.C + grow * g.ldc + gcol;
           *p = *p - acc[i][j][rg];
         }
@@ -170,9 +195,22 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   g.lower_only = lower_only;
   g.tiles_m = (int)((m + GT_BM - 1) / GT_BM);
   g.tiles_n = (int)((n + GT_BN - 1) / GT_BN);
-  const unsigned grid = (unsigned)g.tiles_m * (unsigned)g.tiles_n;
-  if (b_is_kn) hipLaunchKernelGGL(gemm_minus_kernel<1>, dim3(grid), dim3(256), 0, ctx->stream, g);
-  else hipLaunchKernelGGL(gemm_minus_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, g);
+  if (lower_only && g.tiles_m < g.tiles_n) g.tiles_n = g.tiles_m;   /* columns right of the square part are all above the diagonal */
+  unsigned grid = (unsigned)g.tiles_m * (unsigned)g.tiles_n;
+  if (lower_only) {
+    const unsigned tn_ = (unsigned)g.tiles_n;
+    grid = tn_ * (tn_ + 1) / 2 + ((unsigned)g.tiles_m - tn_) * tn_;
+  }
+  g.n_active = grid;
+  const bool full = (m % GT_BM == 0) && (n % GT_BN == 0) && (k % GT_BK == 0) && ((lda & 1) == 0) && ((ldb & 1) == 0) &&
+                    ((((uintptr_t)A) & 15) == 0) && ((((uintptr_t)B) & 15) == 0);
+  if (b_is_kn) {
+    if (full) hipLaunchKernelGGL((gemm_minus_kernel<1, true>), dim3(grid), dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((gemm_minus_kernel<1, false>), dim3(grid), dim3(256), 0, ctx->stream, g);
+  } else {
+    if (full) hipLaunchKernelGGL((gemm_minus_kernel<0, true>), dim3(grid), dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((gemm_minus_kernel<0, false>), dim3(grid), dim3(256), 0, ctx->stream, g);
+  }
   LAUNCH_CHECK(ctx);
   return ST_SUCCESS;
 }
