@@ -279,12 +279,15 @@ trsv_sweep_kernel(const double *__restrict__ T, size_t ldt, size_t n, double *__
 #pragma unroll
     for (int r = 0; r < TRSV_MAXR; r++) acc[r] = 0.0;
     if (i < j0) {
-      const int jb = jg * 16, je = (jb + 16 < nb) ? jb + 16 : nb;
-      for (int j = jb; j < je; j++) {
-        const double t = T[(j0 + j) * ldt + i];                     /* coalesced across lanes */
+      const int jb = jg * 16;
+      double t[16];
 #pragma unroll
-        for (int r = 0; r < TRSV_MAXR; r++) if (r < nrhs) acc[r] = fma(t, sx[r][j], acc[r]);
-      }
+      for (int jj = 0; jj < 16; jj++)                                /* 16 independent loads in flight */
+        t[jj] = (jb + jj < nb) ? T[(j0 + jb + jj) * ldt + i] : 0.0;  /* coalesced across lanes */
+#pragma unroll
+      for (int jj = 0; jj < 16; jj++)
+#pragma unroll
+        for (int r = 0; r < TRSV_MAXR; r++) if (r < nrhs) acc[r] = fma(t[jj], sx[r][jb + jj], acc[r]);
     }
 #pragma unroll
     for (int r = 0; r < TRSV_MAXR; r++) if (r < nrhs) s_part[r][jg][il] = acc[r];
@@ -337,18 +340,158 @@ trsv_sweep_kernel(const double *__restrict__ T, size_t ldt, size_t n, double *__
   }
 }
 
+/* ---- inverse of every 64x64 diagonal block, all blocks in parallel -----------------------
+   The block is read as a LOWER triangular matrix Lb (for an upper factor: its transpose).
+   Lane c solves Lb x = e_c by forward substitution with x in registers (no cross-lane
+   traffic, Lb broadcast from LDS).  Dinv[blk][i][c] = (Lb^-1)[i][c]. */
+__global__ void __launch_bounds__(64)
+tri_inv_kernel(const double *__restrict__ T, size_t ldt, size_t n, int upper, int unit, double *__restrict__ Dinv)
+{
+  __shared__ double sL[TS][TS + 1];
+  const size_t j0 = (size_t)blockIdx.x * TS;
+  const int nb = (int)((n - j0) < TS ? (n - j0) : TS);
+  const int lane = threadIdx.x;
+  for (int r = 0; r < TS; r++) {
+    double v = (r == lane) ? 1.0 : 0.0;                       /* identity padding past nb */
+    if (r < nb && lane < nb) {
+      if (lane < r) v = upper ? T[(j0 + lane) * ldt + j0 + r] : T[(j0 + r) * ldt + j0 + lane];
+      else if (lane == r) v = unit ? 1.0 : T[(j0 + r) * ldt + j0 + r];
+      else v = 0.0;
+    }
+    sL[r][lane] = v;
+  }
+  __syncthreads();
+  double x[TS];
+#pragma unroll
+  for (int i = 0; i < TS; i++) {
+    double v = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; k++) v = fma(-sL[i][k], x[k], v);
+    x[i] = v / sL[i][i];
+  }
+  double *out = Dinv + (size_t)blockIdx.x * TS * TS;
+#pragma unroll
+  for (int i = 0; i < TS; i++) out[(size_t)i * TS + lane] = x[i];   /* coalesced: row i, column = lane */
+}
+
+/* sweep step with precomputed diagonal-block inverses: x_J = W b_J, W = Dinv (mode 0) or Dinv^T
+   (modes 1, 2), then the remaining right-hand side is updated exactly as in trsv_sweep_kernel.
+   The matrix entries of the update are fetched BEFORE x_J is formed, so the launch has one
+   global round trip on its critical path. */
+__global__ void __launch_bounds__(256)
+trsv_sweep_inv_kernel(const double *__restrict__ T, size_t ldt, size_t n, double *__restrict__ b,
+                      double *__restrict__ xout, size_t ldb, int nrhs, size_t j0, int nb, int mode,
+                      const double *__restrict__ Dinv)
+{
+  __shared__ double sx[TRSV_MAXR][TS];
+  __shared__ double sb[TRSV_MAXR][TS];
+  __shared__ double sW[TS][TS + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  /* ---- prefetch this thread's slice of the update operand */
+  double t[16];
+  size_t irow = 0;
+  bool have = false;
+  const int rsub = lane >> 3, c8 = (lane & 7) * 8;
+  if (mode == 1) {
+    irow = (size_t)blockIdx.x * 64 + lane;
+    have = irow < j0;
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++)
+      t[jj] = (have && wave * 16 + jj < nb) ? T[(j0 + wave * 16 + jj) * ldt + irow] : 0.0;
+  } else {
+    const size_t base = (mode == 0) ? j0 + nb : 0;
+    const size_t limit = (mode == 0) ? n : j0;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const size_t i = base + ((size_t)blockIdx.x * 2 + pass) * 32 + wave * 8 + rsub;
+      const double *row = T + i * ldt + j0 + c8;
+#pragma unroll
+      for (int k = 0; k < 8; k++) t[pass * 8 + k] = (i < limit && c8 + k < nb) ? row[k] : 0.0;
+    }
+  }
+  /* ---- x_J = W b_J */
+  const double *D = Dinv + (j0 / TS) * (size_t)(TS * TS);
+  for (int e = tid; e < TS * TS; e += 256) {
+    const int r = e / TS, c = e % TS;
+    sW[r][c] = D[e];
+  }
+  for (int e = tid; e < nrhs * TS; e += 256) {
+    const int r = e / TS, c = e % TS;
+    sb[r][c] = c < nb ? b[r * ldb + j0 + c] : 0.0;
+  }
+  __syncthreads();
+  for (int r = wave; r < nrhs; r += 4) {
+    double acc = 0.0;
+    if (mode == 0) { for (int c = 0; c < TS; c++) acc = fma(sW[lane][c], sb[r][c], acc); }
+    else { for (int c = 0; c < TS; c++) acc = fma(sW[c][lane], sb[r][c], acc); }
+    sx[r][lane] = acc;
+    if (blockIdx.x == 0 && lane < nb) xout[r * ldb + j0 + lane] = acc;
+  }
+  __syncthreads();
+  /* ---- remaining right-hand side */
+  if (mode == 1) {
+    __shared__ double s_part[TRSV_MAXR][4][64];
+#pragma unroll
+    for (int r = 0; r < TRSV_MAXR; r++) {
+      if (r < nrhs) {
+        double acc = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) acc = fma(t[jj], sx[r][wave * 16 + jj], acc);
+        s_part[r][wave][lane] = acc;
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && have) {
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++)
+        if (r < nrhs) b[r * ldb + irow] -= (s_part[r][0][lane] + s_part[r][1][lane]) + (s_part[r][2][lane] + s_part[r][3][lane]);
+    }
+  } else {
+    const size_t base = (mode == 0) ? j0 + nb : 0;
+    const size_t limit = (mode == 0) ? n : j0;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const size_t i = base + ((size_t)blockIdx.x * 2 + pass) * 32 + wave * 8 + rsub;
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++) {
+        if (r < nrhs) {
+          double a = 0.0;
+#pragma unroll
+          for (int k = 0; k < 8; k++) a = fma(t[pass * 8 + k], sx[r][c8 + k], a);
+          a += __shfl_xor(a, 1);
+          a += __shfl_xor(a, 2);
+          a += __shfl_xor(a, 4);
+          if (i < limit && (lane & 7) == 0) b[r * ldb + i] -= a;
+        }
+      }
+    }
+  }
+}
+
 static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout,
-                         size_t ldb, int nrhs, int mode, int unit)
+                         size_t ldb, int nrhs, int mode, int unit, double *d_inv)
 {
   const size_t nblk = (n + TS - 1) / TS;
+  /* single-block systems keep the exact substitution of the reference (cblas/source_trsv_r.h);
+     larger ones multiply by the inverted 64x64 diagonal blocks */
+  const bool use_inv = nblk > 1 && d_inv != NULL;
+  if (use_inv) {
+    hipLaunchKernelGGL(tri_inv_kernel, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, T, ldt, n, mode == 2 ? 1 : 0, unit, d_inv);
+    LAUNCH_CHECK(ctx);
+  }
   for (size_t t = 0; t < nblk; t++) {
     const size_t blk = (mode == 0) ? t : nblk - 1 - t;
     const size_t j0 = blk * TS;
     const int nb = (int)((n - j0) < TS ? (n - j0) : TS);
     const size_t rest = (mode == 0) ? n - j0 - nb : j0;
     const unsigned grid = (unsigned)((rest + 63) / 64);
-    hipLaunchKernelGGL(trsv_sweep_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream, T, ldt, n, b, xout, ldb, nrhs, j0,
-                       nb, mode, unit);
+    if (use_inv)
+      hipLaunchKernelGGL(trsv_sweep_inv_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream, T, ldt, n, b, xout, ldb, nrhs,
+                         j0, nb, mode, (const double *)d_inv);
+    else
+      hipLaunchKernelGGL(trsv_sweep_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream, T, ldt, n, b, xout, ldb, nrhs, j0,
+                         nb, mode, unit);
     LAUNCH_CHECK(ctx);
   }
   return ST_SUCCESS;
@@ -366,10 +509,13 @@ int sinterp_trsv_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size
   int replayed = 0;
   int st = sinterp_graph_try_launch(ctx, slot, n, key_lda, T, p1, &replayed);
   if (st || replayed) return st;
+  void *d_inv = NULL;
+  st = sinterp_invbuf(ctx, ((n + TS - 1) / TS) * TS * TS * sizeof(double), &d_inv);
+  if (st) return st;
   hipStream_t saved;
   st = sinterp_capture_begin(ctx, &saved);
   if (st) return st;
-  st = trsv_launches(ctx, n, T, ldt, b, xout, ldb, nrhs, mode, unit);
+  st = trsv_launches(ctx, n, T, ldt, b, xout, ldb, nrhs, mode, unit, (double *)d_inv);
   int st2 = sinterp_capture_end(ctx, saved, slot, n, key_lda, T, p1);
   return st ? st : st2;
 }

@@ -24,6 +24,8 @@ struct gsl_sinterp_hip_ctx {
   size_t work_bytes;
   void *d_aux;              /* growable buffer of the solver route (right-hand sides, polynomial block) */
   size_t aux_bytes;
+  void *d_inv;              /* inverted 64x64 diagonal blocks of the triangular sweeps */
+  size_t inv_bytes;
   /* hipGraph cache: the recursive factorisation drivers issue ~1-2k small, fully static
      launches; they are captured once per (routine, n, lda, pointers) and replayed */
   hipStream_t cap_stream;
@@ -86,5 +88,6 @@ int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double 
                                int nrhs);
 /* second grow-only buffer for vectors that must outlive factorisation workspaces */
 int sinterp_aux(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
+int sinterp_invbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 
 #endif

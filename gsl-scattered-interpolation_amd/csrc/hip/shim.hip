@@ -66,6 +66,7 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
+  if (ctx->d_inv) (void)hipFree(ctx->d_inv);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -203,6 +204,23 @@ int sinterp_aux(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out)
     ctx->aux_bytes = bytes;
   }
   *out = ctx->d_aux;
+  return ST_SUCCESS;
+}
+
+int sinterp_invbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out)
+{
+  if (bytes > ctx->inv_bytes) {
+    if (ctx->d_inv) {
+      HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_OK(ctx, hipFree(ctx->d_inv));
+      ctx->d_inv = NULL; ctx->inv_bytes = 0;
+      for (int i = 2; i < 4; i++)                      /* cached sweep graphs bake this pointer */
+        if (ctx->graph[i].exec) { (void)hipGraphExecDestroy(ctx->graph[i].exec); ctx->graph[i].exec = NULL; }
+    }
+    HIP_OK(ctx, hipMalloc(&ctx->d_inv, bytes));
+    ctx->inv_bytes = bytes;
+  }
+  *out = ctx->d_inv;
   return ST_SUCCESS;
 }
 
