@@ -146,7 +146,7 @@ def main():
 
                 def init():                               # fill + factorisation + triangular solves
                     st, route = ctx.rbf_solve(kind, eps, d_x.data_ptr(), n, dim, dim, d_phi.data_ptr(), n, d_w.data_ptr())
-                    assert st == 0, (st, route)
+                    assert st == 0, (st, route, pkg.lib().gsl_sinterp_hip_last_error(ctx.handle))
                     route_seen["route"] = route
                 timed("init", init)
             if world > 1:

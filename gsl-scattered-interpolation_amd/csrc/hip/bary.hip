@@ -25,6 +25,7 @@
  */
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 struct __attribute__((aligned(64))) NodeRec {
   double x0, x1;
@@ -159,10 +160,13 @@ __device__ __forceinline__ NodeRec load_rec(const NodeRec *__restrict__ rec, int
 __global__ void __launch_bounds__(256)
 bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, double s0, double s1,
                  const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
-                 int *__restrict__ leaf_out, unsigned long long *__restrict__ n_outside)
+                 int *__restrict__ leaf_out, unsigned long long *__restrict__ n_outside, const int *__restrict__ perm)
 {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+  for (size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x; slot < m; slot += stride) {
+    /* cell-sorted order: the 64 lanes of a wave hold spatial neighbours and descend through
+       (mostly) the same DAG nodes, so their 64-byte gathers coalesce */
+    const size_t k = perm ? (size_t)perm[slot] : slot;
     const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
     /* coords persist across tests exactly like accel->coords in the reference */
     double c0 = 0, c1 = 0;
@@ -259,15 +263,21 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   if (m == 0) return ST_SUCCESS;
   unsigned long long *d_count = (unsigned long long *)ctx->d_scratch;
   HIP_OK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+  int *d_perm = NULL;
+  if (m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1')) {
+    int st = sinterp_sort_targets(ctx, d_targets, m, ttda, 2, 64, &d_perm);
+    if (st) return st;
+  }
   size_t blocks = (m + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(bary_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
                      (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], d_targets, m, ttda,
-                     d_values, d_leaf, d_count);
+                     d_values, d_leaf, d_count, (const int *)d_perm);
   LAUNCH_CHECK(ctx);
   if (h_n_outside) {
     unsigned long long cnt = 0;
-    HIP_OK(ctx, hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
     *h_n_outside = (long long)cnt;
     if (cnt) return sinterp_fail(ctx, ST_EDOM, "bary_eval: target(s) outside the caging simplex", hipSuccess, __FILE__, __LINE__);

@@ -200,10 +200,14 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
     LAUNCH_CHECK(ctx);
   }
   int info = 0;
-  HIP_OK(ctx, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(&info, d_info, sizeof(int), hipMemcpyDeviceToHost));
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
   if (h_info) *h_info = info;
-  if (info) return sinterp_fail(ctx, ST_EDOM, "cholesky_decomp1: matrix is not positive definite", hipSuccess, __FILE__, __LINE__);
+  if (info) {
+    snprintf(ctx->err, sizeof ctx->err, "cholesky_decomp1: matrix is not positive definite (pivot %d of %zu <= 0)", info, n);
+    return ST_EDOM;
+  }
   return ST_SUCCESS;
 }
 

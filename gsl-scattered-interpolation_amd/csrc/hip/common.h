@@ -26,6 +26,8 @@ struct gsl_sinterp_hip_ctx {
   size_t aux_bytes;
   void *d_inv;              /* inverted 64x64 diagonal blocks of the triangular sweeps */
   size_t inv_bytes;
+  void *d_sort;             /* target permutation + cell counters (sort.hip) */
+  size_t sort_bytes;
   /* hipGraph cache: the recursive factorisation drivers issue ~1-2k small, fully static
      launches; they are captured once per (routine, n, lda, pointers) and replayed */
   hipStream_t cap_stream;
@@ -89,5 +91,9 @@ int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double 
 /* second grow-only buffer for vectors that must outlive factorisation workspaces */
 int sinterp_aux(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 int sinterp_invbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
+int sinterp_sortbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
+/* sort.hip: permutation that groups the targets by cell of a uniform grid (~per_cell each) */
+int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
+                         int **d_perm_out);
 
 #endif

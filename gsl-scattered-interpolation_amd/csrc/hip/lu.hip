@@ -581,8 +581,8 @@ extern "C" int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, dou
   int *h_ipiv = (int *)malloc(n * sizeof(int));
   int *h_perm = (int *)malloc(n * sizeof(int));
   if (!h_ipiv || !h_perm) { free(h_ipiv); free(h_perm); return sinterp_fail(ctx, ST_ENOMEM, "lu_decomp: host buffers", hipSuccess, __FILE__, __LINE__); }
-  hipError_t e = hipMemcpyAsync(h_ipiv, d_perm, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(h_ipiv, d_perm, n * sizeof(int), hipMemcpyDeviceToHost);
   int sign = 1;
   if (e == hipSuccess) {
     for (size_t i = 0; i < n; i++) h_perm[i] = (int)i;
@@ -590,8 +590,7 @@ extern "C" int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, dou
       const int p = h_ipiv[k];
       if (p != (int)k && p >= 0 && (size_t)p < n) { int t = h_perm[k]; h_perm[k] = h_perm[p]; h_perm[p] = t; sign = -sign; }
     }
-    e = hipMemcpyAsync(d_perm, h_perm, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    e = hipMemcpy(d_perm, h_perm, n * sizeof(int), hipMemcpyHostToDevice);
   }
   free(h_ipiv); free(h_perm);
   if (e != hipSuccess) return sinterp_fail(ctx, ST_EFAILED, "lu_decomp: pivot transfer", e, __FILE__, __LINE__);
@@ -624,7 +623,8 @@ extern "C" int gsl_sinterp_hip_lu_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const 
   hipLaunchKernelGGL(lu_singular_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_lu, lda, n, d_flag);
   LAUNCH_CHECK(ctx);
   int flag = 0;
-  HIP_OK(ctx, hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost));
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
   if (flag) return sinterp_fail(ctx, ST_EDOM, "lu_svx: matrix is singular", hipSuccess, __FILE__, __LINE__);
 

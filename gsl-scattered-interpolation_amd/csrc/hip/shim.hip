@@ -67,6 +67,7 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->d_inv) (void)hipFree(ctx->d_inv);
+  if (ctx->d_sort) (void)hipFree(ctx->d_sort);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -116,7 +117,8 @@ extern "C" int gsl_sinterp_hip_d2h(gsl_sinterp_hip_ctx *ctx, void *h_dst, const 
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   if (!bytes) return ST_SUCCESS;
-  HIP_OK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
   return ST_SUCCESS;
 }
@@ -221,6 +223,21 @@ int sinterp_invbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out)
     ctx->inv_bytes = bytes;
   }
   *out = ctx->d_inv;
+  return ST_SUCCESS;
+}
+
+int sinterp_sortbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out)
+{
+  if (bytes > ctx->sort_bytes) {
+    if (ctx->d_sort) {
+      HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_OK(ctx, hipFree(ctx->d_sort));
+      ctx->d_sort = NULL; ctx->sort_bytes = 0;
+    }
+    HIP_OK(ctx, hipMalloc(&ctx->d_sort, bytes));
+    ctx->sort_bytes = bytes;
+  }
+  *out = ctx->d_sort;
   return ST_SUCCESS;
 }
 

@@ -191,8 +191,10 @@ extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, dou
     LAUNCH_CHECK(ctx);
     double hG[SV_MAXK * (SV_MAXK + 1)];
     unsigned long long hnorm = 0;
-    HIP_OK(ctx, hipMemcpyAsync(hG, G, sizeof(double) * k * (k + 1), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_OK(ctx, hipMemcpyAsync(&hnorm, d_norm, sizeof hnorm, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(hG, G, sizeof(double) * k * (k + 1), hipMemcpyDeviceToHost));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(&hnorm, d_norm, sizeof hnorm, hipMemcpyDeviceToHost));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
     double nrm;
     memcpy(&nrm, &hnorm, sizeof nrm);

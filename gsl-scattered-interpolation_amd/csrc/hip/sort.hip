@@ -1,0 +1,150 @@
+/*
+ * sort.hip -- spatial binning of evaluation targets (counting sort by grid cell).
+ *
+ * Neither the reference (per-point API, interpolation/linear_simplex.c:331,678) nor the
+ * oracle orders its targets; results per target are independent of the order.  On the GPU
+ * the order decides whether the 64 lanes of a wave walk the same DAG nodes (barycentric) /
+ * see the same negligible Gaussian terms (RBF sweep), so both sweeps process targets
+ * through a permutation that groups them by cell of a uniform grid over their bounding box.
+ * Outputs are written back at the original positions: the caller-visible layout is unchanged.
+ *
+ * Four small kernels: bounding box (atomic min/max on order-preserving integer keys),
+ * histogram, exclusive scan (one workgroup), scatter.  ~1 ms for 10^7 targets.
+ */
+#include "common.h"
+#include <math.h>
+
+__device__ __forceinline__ unsigned long long dkey(double v)   /* monotone double -> uint64 */
+{
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double dunkey(unsigned long long k)
+{
+  unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+__global__ void bbox_init_kernel(unsigned long long *__restrict__ box)
+{
+  if (threadIdx.x < 6) box[threadIdx.x] = (threadIdx.x & 1) ? 0ULL : ~0ULL;
+}
+
+/* box[2c] = min key, box[2c+1] = max key */
+__global__ void __launch_bounds__(256)
+bbox_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, unsigned long long *__restrict__ box)
+{
+  unsigned long long lo[3] = {~0ULL, ~0ULL, ~0ULL}, hi[3] = {0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride)
+    for (int c = 0; c < dim; c++) {
+      const double v = y[k * ytda + c];
+      if (v == v) { const unsigned long long key = dkey(v); lo[c] = key < lo[c] ? key : lo[c]; hi[c] = key > hi[c] ? key : hi[c]; }
+    }
+  for (int c = 0; c < dim; c++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long ol = __shfl_xor(lo[c], off), oh = __shfl_xor(hi[c], off);
+      lo[c] = ol < lo[c] ? ol : lo[c];
+      hi[c] = oh > hi[c] ? oh : hi[c];
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&box[2 * c], lo[c]); atomicMax(&box[2 * c + 1], hi[c]); }
+  }
+}
+
+__device__ __forceinline__ unsigned cell_of(const double *__restrict__ y, size_t k, size_t ytda, int dim, int g,
+                                            const unsigned long long *__restrict__ box)
+{
+  unsigned cell = 0;
+  for (int c = dim - 1; c >= 0; c--) {
+    const double lo = dunkey(box[2 * c]), hi = dunkey(box[2 * c + 1]);
+    const double v = y[k * ytda + c];
+    double f = (hi > lo) ? (v - lo) / (hi - lo) : 0.0;
+    int i = (f == f) ? (int)(f * g) : 0;           /* NaN coordinates go to cell 0 */
+    i = i < 0 ? 0 : (i >= g ? g - 1 : i);
+    cell = cell * (unsigned)g + (unsigned)i;
+  }
+  return cell;
+}
+
+__global__ void __launch_bounds__(256)
+cell_hist_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, int g, const unsigned long long *__restrict__ box,
+                 unsigned *__restrict__ cellid, unsigned *__restrict__ count)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    const unsigned c = cell_of(y, k, ytda, dim, g, box);
+    cellid[k] = c;
+    atomicAdd(&count[c], 1u);
+  }
+}
+
+/* in-place exclusive scan of count[0..ncell) by one workgroup */
+__global__ void __launch_bounds__(1024)
+cell_scan_kernel(unsigned *__restrict__ count, unsigned ncell)
+{
+  __shared__ unsigned s_wave[16];
+  __shared__ unsigned s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (unsigned base = 0; base < ncell; base += 1024) {
+    const unsigned i = base + threadIdx.x;
+    const unsigned v = i < ncell ? count[i] : 0u;
+    unsigned incl = v;
+    for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned woff = 0;
+    for (int w = 0; w < wave; w++) woff += s_wave[w];
+    const unsigned carry = s_carry;
+    if (i < ncell) count[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256)
+cell_scatter_kernel(const unsigned *__restrict__ cellid, size_t m, unsigned *__restrict__ offset, int *__restrict__ perm)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    const unsigned pos = atomicAdd(&offset[cellid[k]], 1u);
+    perm[pos] = (int)k;
+  }
+}
+
+/* perm[i] = index of the i-th target in cell order.  Targets per cell ~ `per_cell`. */
+int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
+                         int **d_perm_out)
+{
+  *d_perm_out = NULL;
+  if (m == 0) return ST_SUCCESS;
+  if (m > 0x7fffffffULL) return sinterp_fail(ctx, ST_EINVAL, "sort_targets: more than 2^31 targets", hipSuccess, __FILE__, __LINE__);
+  double cells = (double)m / (double)(per_cell > 0 ? per_cell : 64);
+  int g = (int)ceil(pow(cells < 1 ? 1.0 : cells, 1.0 / dim));
+  const int gmax = dim == 1 ? (1 << 20) : (dim == 2 ? 1024 : 100);
+  g = g < 1 ? 1 : (g > gmax ? gmax : g);
+  size_t ncell = 1;
+  for (int c = 0; c < dim; c++) ncell *= (size_t)g;
+  void *buf = NULL;
+  const size_t bytes = 64 + m * 4 /*perm*/ + m * 4 /*cellid*/ + ncell * 4;
+  int st = sinterp_sortbuf(ctx, bytes, &buf);
+  if (st) return st;
+  unsigned long long *box = (unsigned long long *)buf;
+  int *perm = (int *)((char *)buf + 64);
+  unsigned *cellid = (unsigned *)(perm + m);
+  unsigned *count = cellid + m;
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, box);   /* no host-sourced async copy */
+  HIP_OK(ctx, hipMemsetAsync(count, 0, ncell * 4, ctx->stream));
+  size_t blocks = (m + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, box);
+  hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g,
+                     (const unsigned long long *)box, cellid, count);
+  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, (unsigned)ncell);
+  hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid, m, count, perm);
+  LAUNCH_CHECK(ctx);
+  *d_perm_out = perm;
+  return ST_SUCCESS;
+}
