@@ -147,10 +147,39 @@ tricpy_lower_to_upper_kernel(double *__restrict__ A, size_t lda, size_t n)
   }
 }
 
-static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, size_t j0, size_t w, int *d_info,
-                      double *d_diag)
+/* Look-ahead.  The update of the right half after a panel is split by columns: the part the
+   next sub-panel needs first (G_a) stays on the main stream, the rest (G_b) runs on an auxiliary
+   stream and is joined just before the recursion touches those columns.  The latency-bound panel
+   kernels of the next sub-panel then overlap with a large MFMA GEMM instead of idling the chip.
+   Under stream capture the fork/join events become edges of the hipGraph. */
+struct Pend { hipEvent_t ev; size_t col; bool active; };
+
+static int la_event(gsl_sinterp_hip_ctx *ctx, hipEvent_t *out)
 {
+  if (ctx->la_events_used >= 4096) return sinterp_fail(ctx, ST_EFAILED, "look-ahead event pool exhausted", hipSuccess, __FILE__, __LINE__);
+  if (ctx->la_events_used >= ctx->la_events_made) {
+    HIP_OK(ctx, hipEventCreateWithFlags(&ctx->la_event[ctx->la_events_made], hipEventDisableTiming));
+    ctx->la_events_made++;
+  }
+  *out = ctx->la_event[ctx->la_events_used++];
+  return ST_SUCCESS;
+}
+
+static int join_pend(gsl_sinterp_hip_ctx *ctx, Pend *p)
+{
+  if (p && p->active) {
+    HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, p->ev, 0));
+    p->active = false;
+  }
+  return ST_SUCCESS;
+}
+
+static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, size_t j0, size_t w, int *d_info,
+                      double *d_diag, int depth, Pend *pend)
+{
+  int st;
   if (w <= CB) {
+    if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
     const size_t below = n - j0 - w;
     const unsigned grid = (unsigned)((below + 255) / 256) + (below == 0 ? 1u : 0u);
     hipLaunchKernelGGL(chol_base_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream, A, lda, n, j0, (int)w, d_info, d_diag);
@@ -159,13 +188,39 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
   }
   size_t w1 = ((w / 2 + CB - 1) / CB) * CB;
   if (w1 >= w) w1 = w - CB;
-  int st = chol_panel(ctx, A, lda, n, j0, w1, d_info, d_diag);
+  st = chol_panel(ctx, A, lda, n, j0, w1, d_info, d_diag, depth + 1, pend);
   if (st) return st;
-  const size_t r0 = j0 + w1;
-  st = sinterp_gemm_minus(ctx, n - r0, w - w1, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0,
-                          A + r0 * lda + r0, lda, 1);
+  if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
+  const size_t r0 = j0 + w1, w2 = w - w1;
+  const bool fork = ctx->use_lookahead && depth < 15 && w1 >= 256 && w2 > CB;
+  if (!fork) {
+    st = sinterp_gemm_minus(ctx, n - r0, w2, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
+    if (st) return st;
+    return chol_panel(ctx, A, lda, n, r0, w2, d_info, d_diag, depth + 1, NULL);
+  }
+  /* same split the recursion on the right half will make */
+  size_t w2a = ((w2 / 2 + CB - 1) / CB) * CB;
+  if (w2a >= w2) w2a = w2 - CB;
+  const size_t w2b = w2 - w2a, rb = r0 + w2a;
+  if (!ctx->la_stream[depth]) HIP_OK(ctx, hipStreamCreateWithFlags(&ctx->la_stream[depth], hipStreamNonBlocking));
+  hipStream_t aux = ctx->la_stream[depth], mainst = ctx->stream;
+  hipEvent_t e_left, e_gb;
+  st = la_event(ctx, &e_left); if (st) return st;
+  st = la_event(ctx, &e_gb); if (st) return st;
+  HIP_OK(ctx, hipEventRecord(e_left, mainst));
+  HIP_OK(ctx, hipStreamWaitEvent(aux, e_left, 0));
+  ctx->stream = aux;                                     /* G_b: columns [rb, r0+w2), rows >= rb */
+  st = sinterp_gemm_minus(ctx, n - rb, w2b, w1, A + rb * lda + j0, lda, A + rb * lda + j0, lda, 0, A + rb * lda + rb, lda, 1);
+  ctx->stream = mainst;
   if (st) return st;
-  return chol_panel(ctx, A, lda, n, r0, w - w1, d_info, d_diag);
+  HIP_OK(ctx, hipEventRecord(e_gb, aux));
+  /* G_a: columns [r0, rb), rows >= r0 */
+  st = sinterp_gemm_minus(ctx, n - r0, w2a, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
+  if (st) return st;
+  Pend mine = {e_gb, rb, true};
+  st = chol_panel(ctx, A, lda, n, r0, w2, d_info, d_diag, depth + 1, &mine);
+  if (st) return st;
+  return join_pend(ctx, &mine);
 }
 
 extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info)
@@ -190,7 +245,8 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
     hipError_t me = hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream);
     const unsigned nt = (unsigned)((n + 31) / 32);
     hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
-    st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag);
+    ctx->la_events_used = 0;
+    st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag, 0, NULL);
     hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
                        (const double *)d_diag);
     int st2 = sinterp_capture_end(ctx, saved, 0, n, lda, d_a, NULL);

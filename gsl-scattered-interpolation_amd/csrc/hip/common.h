@@ -33,6 +33,10 @@ struct gsl_sinterp_hip_ctx {
   hipStream_t cap_stream;
   struct GraphSlot { hipGraphExec_t exec; size_t n, lda; const void *p0, *p1, *work; } graph[4];
   int use_graphs;
+  /* look-ahead: auxiliary streams (one per recursion depth) and an event pool */
+  hipStream_t la_stream[16];
+  hipEvent_t la_event[4096];
+  int la_events_made, la_events_used, use_lookahead;
   char err[512];
 };
 

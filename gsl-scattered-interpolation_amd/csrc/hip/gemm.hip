@@ -20,6 +20,7 @@
  *   B[k=lane>>4][j=lane&15], D[row=(lane>>4)+4*reg][col=lane&15].
  */
 #include "common.h"
+#include <stdlib.h>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -186,6 +187,131 @@ gemm_minus_kernel(GemmArgs g)
   }
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* Full-tile NT variant with direct-to-LDS loads (global_load_lds_dwordx4) and a 3-stage ring:
+   the operand tiles of K-steps s+1 and s+2 are in flight while step s feeds the MFMAs, no VGPR
+   staging, no ds_write pass, one raw s_barrier + one counted vmcnt wait per K-step.
+   LDS image per stage and operand: 128 rows x 16 doubles, unpadded (a DMA wave-instruction writes
+   1 KiB linearly = 8 rows), 16-byte slot index XOR-swizzled with (row>>1)&7 -- applied to the
+   per-lane SOURCE address of the DMA and to the fragment read, so the (row = lane&15,
+   k = lane>>4) ds_read_b64 stays bank-conflict free. */
+#define DM_STAGES 3
+#define DM_TILE (GT_BM * GT_BK) /* 2048 doubles = 16 KiB */
+
+__device__ __forceinline__ void dma16(const double *gsrc, double *ldst)
+{
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 1)
+gemm_minus_dma_nt_kernel(GemmArgs g)
+{
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *sA = smem;                                   /* [DM_STAGES][DM_TILE] */
+  double *sB = smem + DM_STAGES * DM_TILE;
+
+  const unsigned nwg = gridDim.x, bid = blockIdx.x;
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+  const unsigned tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  int tm, tn;
+  if (!g.lower_only) {
+    tm = (int)(tile / g.tiles_n); tn = (int)(tile % g.tiles_n);
+  } else {
+    const unsigned tri = (unsigned)g.tiles_n * (unsigned)(g.tiles_n + 1) / 2;
+    if (tile < tri) {
+      tm = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+      while ((unsigned)(tm + 1) * (unsigned)(tm + 2) / 2 <= tile) tm++;
+      while ((unsigned)tm * (unsigned)(tm + 1) / 2 > tile) tm--;
+      tn = (int)(tile - (unsigned)tm * (unsigned)(tm + 1) / 2);
+    } else {
+      const unsigned t2 = tile - tri;
+      tm = g.tiles_n + (int)(t2 / g.tiles_n); tn = (int)(t2 % g.tiles_n);
+    }
+  }
+  const size_t row0 = (size_t)tm * GT_BM, col0 = (size_t)tn * GT_BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  /* DMA source addresses of this lane: chunk c = wave*4 + i covers rows 8c..8c+7 */
+  const double *srcA[4], *srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = wave * 4 + i;
+    const int rr = c * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((rr >> 1) & 7);
+    srcA[i] = g.A + (row0 + rr) * g.lda + slot * 2;
+    srcB[i] = g.B + (col0 + rr) * g.ldb + slot * 2;
+  }
+  auto issue = [&](int stage, size_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = wave * 4 + i;
+      dma16(srcA[i] + k0, sA + stage * DM_TILE + c * 128);
+      dma16(srcB[i] + k0, sB + stage * DM_TILE + c * 128);
+    }
+  };
+
+  /* fragment read offsets (doubles) within a stage: row*16 + ((slot ^ sw)*2 + (k&1)) */
+  const int sw = (fr >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) koff[kk] = (((kk * 2 + (fq >> 1)) ^ sw) << 1) + (fq & 1);
+  const int arow = (wr * 64 + fr) * GT_BK, brow = (wc * 64 + fr) * GT_BK;
+
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const size_t nsteps = g.k / GT_BK;
+  issue(0, 0);
+  if (nsteps > 1) issue(1, GT_BK);
+
+  for (size_t s = 0; s < nsteps; s++) {
+    /* stage s has landed once at most the 8 DMAs of stage s+1 are still outstanding */
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < nsteps) issue((int)((s + 2) % DM_STAGES), (s + 2) * GT_BK);   /* ring slot read at step s-1 */
+    const double *a_base = sA + (s % DM_STAGES) * DM_TILE + arow;
+    const double *b_base = sB + (s % DM_STAGES) * DM_TILE + brow;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) af[i] = a_base[i * 16 * GT_BK + koff[kk]];
+#pragma unroll
+      for (int j = 0; j < 4; j++) bf[j] = b_base[j * 16 * GT_BK + koff[kk]];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const size_t gcol = col0 + wc * 64 + j * 16 + fr;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const size_t grow = row0 + wr * 64 + i * 16 + fq + 4 * rg;
+        if (!g.lower_only || gcol <= grow) {
+          double *p = g.C + grow * g.ldc + gcol;
+          *p = *p - acc[i][j][rg];
+        }
+      }
+    }
+  }
+}
+
 int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, const double *A, size_t lda,
                        const double *B, size_t ldb, int b_is_kn, double *C, size_t ldc, int lower_only)
 {
@@ -204,6 +330,18 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   g.n_active = grid;
   const bool full = (m % GT_BM == 0) && (n % GT_BN == 0) && (k % GT_BK == 0) && ((lda & 1) == 0) && ((ldb & 1) == 0) &&
                     ((((uintptr_t)A) & 15) == 0) && ((((uintptr_t)B) & 15) == 0);
+  static const bool no_dma = getenv("GSL_SINTERP_NO_DMA_GEMM") && getenv("GSL_SINTERP_NO_DMA_GEMM")[0] == '1';
+  if (full && !b_is_kn && k >= 4 * GT_BK && !no_dma) {
+    const size_t lds = 2 * DM_STAGES * DM_TILE * sizeof(double);     /* 96 KiB */
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_dma_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_minus_dma_nt_kernel, dim3(grid), dim3(256), lds, ctx->stream, g);
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
   if (b_is_kn) {
     if (full) hipLaunchKernelGGL((gemm_minus_kernel<1, true>), dim3(grid), dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL((gemm_minus_kernel<1, false>), dim3(grid), dim3(256), 0, ctx->stream, g);

@@ -38,7 +38,7 @@ def test_cholesky_decomp_and_solve(pkg, orc, n):
     rec = L @ L.T
     if n <= 64:
         assert np.all(np.abs(rec - a) <= 100.0 * n * EPS * np.abs(a))  # linalg/test_cholesky.c:59-135 (N <= 50 there)
-    assert np.abs(rec - a).max() <= 10.0 * EPS * np.abs(a).max()        # norm-wise backward error at any N
+    assert np.abs(rec - a).max() <= (10.0 + n / 20.0) * EPS * np.abs(a).max()   # norm-wise backward error (bound ~ n eps |A|)
     d_x = dev(b)
     ctx.cholesky_svx(n, ptr(d_a), lda, ptr(d_x))
     ctx.sync()
