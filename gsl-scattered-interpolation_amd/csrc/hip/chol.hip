@@ -40,6 +40,22 @@ chol_base_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int nb
   __shared__ double sInv[CB];
   const int tid = threadIdx.x;
 
+  /* this thread's row of the panel: the loads are issued before the serial factorisation so
+     their latency hides behind it */
+  const size_t row = j0 + nb + (size_t)blockIdx.x * blockDim.x + tid;
+  double *p = A + row * lda + j0;
+  double x[CB];
+  const bool vecrow = nb == CB && ((((uintptr_t)p) & 15) == 0) && ((lda & 1) == 0);
+  if (row < n) {
+    if (vecrow) {
+#pragma unroll
+      for (int k = 0; k < CB; k += 2) { const double2 t = *reinterpret_cast<const double2 *>(p + k); x[k] = t.x; x[k + 1] = t.y; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < CB; k++) x[k] = k < nb ? p[k] : 0.0;
+    }
+  }
+
   if (tid < 64) {                                  /* one wave factors the diagonal block */
     const int lane = tid;
     double a[CB];
@@ -88,20 +104,7 @@ chol_base_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int nb
   __syncthreads();
 
   /* rows below the diagonal block: x L^T = b, one row per thread, row in registers */
-  const size_t row = j0 + nb + (size_t)blockIdx.x * blockDim.x + tid;
   if (row >= n) return;
-  double *p = A + row * lda + j0;
-  double x[CB];
-  if (nb == CB && ((((uintptr_t)p) & 15) == 0)) {
-#pragma unroll
-    for (int k = 0; k < CB; k += 2) {
-      double2 t = *reinterpret_cast<const double2 *>(p + k);
-      x[k] = t.x; x[k + 1] = t.y;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < CB; k++) x[k] = k < nb ? p[k] : 0.0;
-  }
 #pragma unroll
   for (int j = 0; j < CB; j++) {
     double v = x[j];
@@ -109,7 +112,7 @@ chol_base_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int nb
     for (int k = 0; k < j; k++) v = fma(-x[k], sL[j][k], v);
     x[j] = v * sInv[j];
   }
-  if (nb == CB && ((((uintptr_t)p) & 15) == 0)) {
+  if (vecrow) {
 #pragma unroll
     for (int k = 0; k < CB; k += 2) *reinterpret_cast<double2 *>(p + k) = make_double2(x[k], x[k + 1]);
   } else {

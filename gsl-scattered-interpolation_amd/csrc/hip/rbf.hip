@@ -21,10 +21,12 @@
 
 /* tables live in global memory (built once per context on first use) and are
    copied into LDS by each workgroup */
+#define LOG_BITS 10
+#define LOG_N (1 << LOG_BITS)
 struct RbfTables {
-  double exp2_frac[TBL_N];      /* 2^(i/256)                        */
-  double log_inv[TBL_N];        /* 1/c_i, c_i = 1 + (i+0.5)/256     */
-  double log_val[TBL_N];        /* ln c_i                           */
+  double exp2_frac[TBL_N];      /* 2^(i/256)                          */
+  double log_inv[LOG_N];        /* 1/c_i, c_i = 1 + (i+0.5)/1024      */
+  double log_val[LOG_N];        /* ln c_i                             */
 };
 
 __device__ RbfTables g_rbf_tables;
@@ -34,9 +36,9 @@ static int ensure_tables(gsl_sinterp_hip_ctx *ctx)
 {
   if (ctx->device < 64 && g_tables_ready[ctx->device]) return ST_SUCCESS;
   static RbfTables h;
-  for (int i = 0; i < TBL_N; i++) {
-    h.exp2_frac[i] = exp2((double)i / TBL_N);
-    double c = 1.0 + ((double)i + 0.5) / TBL_N;
+  for (int i = 0; i < TBL_N; i++) h.exp2_frac[i] = exp2((double)i / TBL_N);
+  for (int i = 0; i < LOG_N; i++) {
+    double c = 1.0 + ((double)i + 0.5) / LOG_N;
     h.log_inv[i] = 1.0 / c;
     h.log_val[i] = log(c);
   }
@@ -63,18 +65,16 @@ __device__ __forceinline__ double exp2_tbl(double t, const double *__restrict__ 
   return ldexp(tbl[k & (TBL_N - 1)] * p, k >> TBL_BITS);
 }
 
-/* ln(v), v > 0 finite normal: v = 2^e m, m in [1,2); u = m/c - 1, |u| <= 2^-9 */
+/* ln(v), v > 0 finite normal: v = 2^e m, m in [1,2), split with integer ops on the high word;
+   table index = top 10 mantissa bits, u = m/c - 1, |u| <= 2^-11, log1p(u) to u^4 (|u|^5/5 < 6e-18) */
 __device__ __forceinline__ double log_tbl(double v, const double *__restrict__ inv, const double *__restrict__ val)
 {
-  int e;
-  double m = frexp(v, &e);                         /* m in [0.5,1) */
-  m *= 2.0; e -= 1;
-  const int idx = (int)((m - 1.0) * (double)TBL_N);
+  const int hi = __double2hiint(v), lo = __double2loint(v);
+  const int e = (hi >> 20) - 1023;
+  const int idx = (hi >> (20 - LOG_BITS)) & (LOG_N - 1);
+  const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
   const double u = fma(m, inv[idx], -1.0);
-  /* log1p(u) = u - u^2/2 + u^3/3 - u^4/4 + u^5/5 - u^6/6, |u|^7/7 < 1.5e-20 */
-  double p = fma(u, -1.0 / 6.0, 0.2);
-  p = fma(p, u, -0.25);
-  p = fma(p, u, 1.0 / 3.0);
+  double p = fma(u, -0.25, 1.0 / 3.0);
   p = fma(p, u, -0.5);
   p = fma(p, u, 1.0);
   return fma((double)e, 0.693147180559945309417232, fma(p, u, val[idx]));
@@ -87,17 +87,19 @@ __device__ __forceinline__ double phi_r2(double r2, double coef, const double *_
   if (KIND == GSL_SINTERP_RBF_GAUSSIAN) {
     return exp2_tbl(r2 * coef, t0);                /* coef = -eps^2 log2(e) */
   } else {
-    double l = log_tbl(fmax(r2, 1e-300), t1, t2);
-    double v = (0.5 * r2) * l;                     /* r^2 ln r */
-    return r2 > 0.0 ? v : 0.0;
+    /* r^2 ln r = 0.5 r^2 ln r^2; the 0.5 is folded into the caller's weight (coef = 0.5 in fill).
+       r2 = 0 (target on a centre): clamped to 1e-300, phi = -7e-298, i.e. 0 to any tolerance */
+    const double rc = fmax(r2, 1e-300);
+    return (coef * rc) * log_tbl(rc, t1, t2);
   }
 }
 
 __device__ __forceinline__ void load_tables(double *s_t0, double *s_t1, double *s_t2, int kind)
 {
-  for (int i = threadIdx.x; i < TBL_N; i += blockDim.x) {
-    if (kind == GSL_SINTERP_RBF_GAUSSIAN) s_t0[i] = g_rbf_tables.exp2_frac[i];
-    else { s_t1[i] = g_rbf_tables.log_inv[i]; s_t2[i] = g_rbf_tables.log_val[i]; }
+  if (kind == GSL_SINTERP_RBF_GAUSSIAN) {
+    for (int i = threadIdx.x; i < TBL_N; i += blockDim.x) s_t0[i] = g_rbf_tables.exp2_frac[i];
+  } else {
+    for (int i = threadIdx.x; i < LOG_N; i += blockDim.x) { s_t1[i] = g_rbf_tables.log_inv[i]; s_t2[i] = g_rbf_tables.log_val[i]; }
   }
 }
 
@@ -107,7 +109,7 @@ template <int KIND, int DIM>
 __global__ void __launch_bounds__(256)
 rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, double *__restrict__ phi, size_t lda)
 {
-  __shared__ double s_t0[TBL_N], s_t1[TBL_N], s_t2[TBL_N];
+  __shared__ double s_t0[TBL_N], s_t1[KIND == GSL_SINTERP_RBF_TPS ? LOG_N : 1], s_t2[KIND == GSL_SINTERP_RBF_TPS ? LOG_N : 1];
   load_tables(s_t0, s_t1, s_t2, KIND);
   __syncthreads();
   const size_t j0 = ((size_t)blockIdx.x * 64 + (threadIdx.x & 63)) * 2;
@@ -128,8 +130,9 @@ rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
       const double da = xi - xa[c], db = xi - xb[c];
       ra = fma(da, da, ra); rb = fma(db, db, rb);
     }
-    const double va = phi_r2<KIND>(ra, coef, s_t0, s_t1, s_t2);
-    const double vb = phi_r2<KIND>(rb, coef, s_t0, s_t1, s_t2);
+    double va = phi_r2<KIND>(ra, coef, s_t0, s_t1, s_t2);
+    double vb = phi_r2<KIND>(rb, coef, s_t0, s_t1, s_t2);
+    if (KIND == GSL_SINTERP_RBF_TPS) { va = ra > 0.0 ? va : 0.0; vb = rb > 0.0 ? vb : 0.0; }   /* phi(0) = 0 exactly in the matrix */
     double *dst = phi + i * lda + j0;
     if (two && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<double2 *>(dst) = make_double2(va, vb);
     else { dst[0] = va; if (two) dst[1] = vb; }
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(EV_THREADS)
 rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, const double *__restrict__ w,
                 const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm)
 {
-  __shared__ double s_t0[TBL_N], s_t1[TBL_N], s_t2[TBL_N];
+  __shared__ double s_t0[TBL_N], s_t1[KIND == GSL_SINTERP_RBF_TPS ? LOG_N : 1], s_t2[KIND == GSL_SINTERP_RBF_TPS ? LOG_N : 1];
   __shared__ double s_c[EV_TJ * (DIM + 1)];       /* per centre: x[0..DIM-1], w */
   load_tables(s_t0, s_t1, s_t2, KIND);
 
@@ -170,7 +173,7 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
     for (int e = threadIdx.x; e < cnt; e += EV_THREADS) {
 #pragma unroll
       for (int c = 0; c < DIM; c++) s_c[e * (DIM + 1) + c] = x[(jt + e) * xtda + c];
-      s_c[e * (DIM + 1) + DIM] = w[jt + e];
+      s_c[e * (DIM + 1) + DIM] = (KIND == GSL_SINTERP_RBF_TPS ? 0.5 : 1.0) * w[jt + e];
     }
     __syncthreads();
 #pragma unroll 2
@@ -197,7 +200,8 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
       }
 #pragma unroll
-      for (int t = 0; t < TPT; t++) acc[t] = fma(wj, phi_r2<KIND>(r2[t], coef, s_t0, s_t1, s_t2), acc[t]);
+      for (int t = 0; t < TPT; t++)
+        acc[t] = fma(wj, phi_r2<KIND>(r2[t], KIND == GSL_SINTERP_RBF_TPS ? 1.0 : coef, s_t0, s_t1, s_t2), acc[t]);
     }
   }
 #pragma unroll
@@ -208,7 +212,7 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
 /* ------------------------------------------------------------------------ */
 static double kernel_coef(int kind, double eps)
 {
-  return kind == GSL_SINTERP_RBF_GAUSSIAN ? -(eps * eps) * 1.44269504088896340735992 : 0.0;
+  return kind == GSL_SINTERP_RBF_GAUSSIAN ? -(eps * eps) * 1.44269504088896340735992 : 0.5;
 }
 
 template <int KIND>
