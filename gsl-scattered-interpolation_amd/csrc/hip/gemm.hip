@@ -312,6 +312,77 @@ gemm_minus_dma_nt_kernel(GemmArgs g)
   }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Small-K, skinny-N update (the K = 32 / 64 levels of the recursions): C[m x BN] -= A[m x K] B^T,
+   B stored [BN][K], K <= 64.  Everything a workgroup needs -- its 128 x K slice of A, all of B and
+   its C tile -- is fetched in ONE global round trip; the A slice is negated on its way into LDS
+   and the accumulators start as C, so the epilogue is a plain store. */
+template <int BN>
+__global__ void __launch_bounds__(256)
+gemm_minus_smallk_kernel(GemmArgs g)
+{
+  constexpr int NF = BN / 16;                  /* n fragments per wave */
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int K = (int)g.k, LD = K + 2;
+  double *sA = smem;                           /* [128][LD] */
+  double *sB = smem + 128 * LD;                /* [BN][LD]  */
+  const size_t row0 = (size_t)blockIdx.x * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int kch = K / 2;                       /* 16-byte chunks per row */
+
+  /* C tile -> accumulators (row clamped, masked later) */
+  double4_t acc[2][NF];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < NF; j++) {
+      const size_t gcol = j * 16 + fr;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const size_t grow = row0 + wave * 32 + i * 16 + fq + 4 * rg;
+        const size_t rcl = grow < g.m ? grow : g.m - 1;
+        acc[i][j][rg] = g.C[rcl * g.ldc + gcol];
+      }
+    }
+  /* operands -> LDS */
+  for (int c = tid; c < 128 * kch; c += 256) {
+    const int rr = c / kch, kc = (c % kch) * 2;
+    const size_t grow = row0 + rr, rcl = grow < g.m ? grow : g.m - 1;
+    const double2 v = *reinterpret_cast<const double2 *>(g.A + rcl * g.lda + kc);
+    *reinterpret_cast<double2 *>(&sA[rr * LD + kc]) = make_double2(-v.x, -v.y);
+  }
+  for (int c = tid; c < BN * kch; c += 256) {
+    const int rr = c / kch, kc = (c % kch) * 2;
+    *reinterpret_cast<double2 *>(&sB[rr * LD + kc]) = *reinterpret_cast<const double2 *>(g.B + (size_t)rr * g.ldb + kc);
+  }
+  __syncthreads();
+  const double *a_base = sA + (wave * 32 + fr) * LD + fq;
+  const double *b_base = sB + fr * LD + fq;
+  for (int kk = 0; kk < K; kk += 4) {
+    double af[2], bf[NF];
+#pragma unroll
+    for (int i = 0; i < 2; i++) af[i] = a_base[i * 16 * LD + kk];
+#pragma unroll
+    for (int j = 0; j < NF; j++) bf[j] = b_base[j * 16 * LD + kk];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < NF; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < NF; j++) {
+      const size_t gcol = j * 16 + fr;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const size_t grow = row0 + wave * 32 + i * 16 + fq + 4 * rg;
+        if (grow < g.m && (!g.lower_only || gcol <= grow)) g.C[grow * g.ldc + gcol] = acc[i][j][rg];
+      }
+    }
+}
+
 int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, const double *A, size_t lda,
                        const double *B, size_t ldb, int b_is_kn, double *C, size_t ldc, int lower_only)
 {
@@ -330,6 +401,21 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   g.n_active = grid;
   const bool full = (m % GT_BM == 0) && (n % GT_BN == 0) && (k % GT_BK == 0) && ((lda & 1) == 0) && ((ldb & 1) == 0) &&
                     ((((uintptr_t)A) & 15) == 0) && ((((uintptr_t)B) & 15) == 0);
+  /* skinny small-K update: one round trip */
+  if (!b_is_kn && (n == 32 || n == 64) && k <= 64 && (k % 4) == 0 && k >= 4 && ((lda & 1) == 0) && ((ldb & 1) == 0) &&
+      ((((uintptr_t)A) & 15) == 0) && ((((uintptr_t)B) & 15) == 0)) {
+    const size_t lds = (size_t)(128 + n) * (k + 2) * sizeof(double);
+    static bool attr32 = false, attr64 = false;
+    if (n == 32) {
+      if (!attr32) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_smallk_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr32 = true; }
+      hipLaunchKernelGGL(gemm_minus_smallk_kernel<32>, dim3((unsigned)g.tiles_m), dim3(256), lds, ctx->stream, g);
+    } else {
+      if (!attr64) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_smallk_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr64 = true; }
+      hipLaunchKernelGGL(gemm_minus_smallk_kernel<64>, dim3((unsigned)g.tiles_m), dim3(256), lds, ctx->stream, g);
+    }
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
   static const bool no_dma = getenv("GSL_SINTERP_NO_DMA_GEMM") && getenv("GSL_SINTERP_NO_DMA_GEMM")[0] == '1';
   if (full && !b_is_kn && k >= 4 * GT_BK && !no_dma) {
     const size_t lds = 2 * DM_STAGES * DM_TILE * sizeof(double);     /* 96 KiB */
