@@ -41,13 +41,23 @@ bbox_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, unsign
       const double v = y[k * ytda + c];
       if (v == v) { const unsigned long long key = dkey(v); lo[c] = key < lo[c] ? key : lo[c]; hi[c] = key > hi[c] ? key : hi[c]; }
     }
+  /* wave reduce -> workgroup reduce in LDS -> one atomic pair per workgroup and coordinate */
+  __shared__ unsigned long long s_lo[3][4], s_hi[3][4];
   for (int c = 0; c < dim; c++) {
     for (int off = 32; off > 0; off >>= 1) {
       const unsigned long long ol = __shfl_xor(lo[c], off), oh = __shfl_xor(hi[c], off);
       lo[c] = ol < lo[c] ? ol : lo[c];
       hi[c] = oh > hi[c] ? oh : hi[c];
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&box[2 * c], lo[c]); atomicMax(&box[2 * c + 1], hi[c]); }
+    if ((threadIdx.x & 63) == 0) { s_lo[c][threadIdx.x >> 6] = lo[c]; s_hi[c][threadIdx.x >> 6] = hi[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < dim) {
+    const int c = threadIdx.x;
+    unsigned long long l = s_lo[c][0], h = s_hi[c][0];
+    for (int w = 1; w < 4; w++) { l = s_lo[c][w] < l ? s_lo[c][w] : l; h = s_hi[c][w] > h ? s_hi[c][w] : h; }
+    atomicMin(&box[2 * c], l);
+    atomicMax(&box[2 * c + 1], h);
   }
 }
 
@@ -139,7 +149,7 @@ int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   HIP_OK(ctx, hipMemsetAsync(count, 0, ncell * 4, ctx->stream));
   size_t blocks = (m + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, box);
+  hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, box);
   hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g,
                      (const unsigned long long *)box, cellid, count);
   hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, (unsigned)ncell);
