@@ -197,7 +197,6 @@ gemm_minus_kernel(GemmArgs g)
    per-lane SOURCE address of the DMA and to the fragment read, so the (row = lane&15,
    k = lane>>4) ds_read_b64 stays bank-conflict free. */
 #define DM_STAGES 3
-#define DM_TILE (GT_BM * GT_BK) /* 2048 doubles = 16 KiB */
 
 __device__ __forceinline__ void dma16(const double *gsrc, double *ldst)
 {
@@ -205,12 +204,19 @@ __device__ __forceinline__ void dma16(const double *gsrc, double *ldst)
                                    (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
 }
 
-__global__ void __launch_bounds__(256, 1)
+/* WR = wave rows: 2 -> 128x128 tile, 4 waves, 1 wave/SIMD;  4 -> 256x128 tile, 8 waves, 2 waves/SIMD
+   (a wave's DMA issue / wait gaps are then covered by its SIMD partner's MFMAs). */
+template <int WR>
+__global__ void __launch_bounds__(128 * WR, 1)
 gemm_minus_dma_nt_kernel(GemmArgs g)
 {
+  constexpr int BM = 64 * WR;
+  constexpr int NW = 2 * WR;                           /* waves */
+  constexpr int A_TILE = BM * GT_BK, B_TILE = GT_BN * GT_BK;
+  constexpr int A_CH = BM / 8 / NW, B_CH = (GT_BN / 8) / NW;   /* 1-KiB chunks per wave: 4,4 or 4,2 */
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double *sA = smem;                                   /* [DM_STAGES][DM_TILE] */
-  double *sB = smem + DM_STAGES * DM_TILE;
+  double *sA = smem;                                   /* [DM_STAGES][A_TILE] */
+  double *sB = smem + DM_STAGES * A_TILE;
 
   const unsigned nwg = gridDim.x, bid = blockIdx.x;
   const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8;
@@ -219,39 +225,43 @@ gemm_minus_dma_nt_kernel(GemmArgs g)
   if (!g.lower_only) {
     tm = (int)(tile / g.tiles_n); tn = (int)(tile % g.tiles_n);
   } else {
-    const unsigned tri = (unsigned)g.tiles_n * (unsigned)(g.tiles_n + 1) / 2;
+    /* row tm of tiles holds min(R*(tm+1), tiles_n) active tiles, R = BM/128 */
+    constexpr unsigned R = BM / GT_BN;
+    const unsigned full_rows = (unsigned)g.tiles_n / R;             /* rows of the triangular part */
+    const unsigned tri = R * full_rows * (full_rows + 1) / 2;
     if (tile < tri) {
-      tm = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
-      while ((unsigned)(tm + 1) * (unsigned)(tm + 2) / 2 <= tile) tm++;
-      while ((unsigned)tm * (unsigned)(tm + 1) / 2 > tile) tm--;
-      tn = (int)(tile - (unsigned)tm * (unsigned)(tm + 1) / 2);
+      const double t = (double)tile / (double)R;
+      tm = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+      while (R * (unsigned)(tm + 1) * (unsigned)(tm + 2) / 2 <= tile) tm++;
+      while (R * (unsigned)tm * (unsigned)(tm + 1) / 2 > tile) tm--;
+      tn = (int)(tile - R * (unsigned)tm * (unsigned)(tm + 1) / 2);
     } else {
       const unsigned t2 = tile - tri;
-      tm = g.tiles_n + (int)(t2 / g.tiles_n); tn = (int)(t2 % g.tiles_n);
+      tm = (int)full_rows + (int)(t2 / g.tiles_n); tn = (int)(t2 % g.tiles_n);
     }
   }
-  const size_t row0 = (size_t)tm * GT_BM, col0 = (size_t)tn * GT_BN;
+  const size_t row0 = (size_t)tm * BM, col0 = (size_t)tn * GT_BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
 
-  /* DMA source addresses of this lane: chunk c = wave*4 + i covers rows 8c..8c+7 */
-  const double *srcA[4], *srcB[4];
+  /* DMA source addresses of this lane */
+  const double *srcA[A_CH], *srcB[B_CH];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int c = wave * 4 + i;
-    const int rr = c * 8 + (lane >> 3);
-    const int slot = (lane & 7) ^ ((rr >> 1) & 7);
-    srcA[i] = g.A + (row0 + rr) * g.lda + slot * 2;
-    srcB[i] = g.B + (col0 + rr) * g.ldb + slot * 2;
+  for (int i = 0; i < A_CH; i++) {
+    const int rr = (wave * A_CH + i) * 8 + (lane >> 3);
+    srcA[i] = g.A + (row0 + rr) * g.lda + (((lane & 7) ^ ((rr >> 1) & 7)) << 1);
+  }
+#pragma unroll
+  for (int i = 0; i < B_CH; i++) {
+    const int rr = (wave * B_CH + i) * 8 + (lane >> 3);
+    srcB[i] = g.B + (col0 + rr) * g.ldb + (((lane & 7) ^ ((rr >> 1) & 7)) << 1);
   }
   auto issue = [&](int stage, size_t k0) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int c = wave * 4 + i;
-      dma16(srcA[i] + k0, sA + stage * DM_TILE + c * 128);
-      dma16(srcB[i] + k0, sB + stage * DM_TILE + c * 128);
-    }
+    for (int i = 0; i < A_CH; i++) dma16(srcA[i] + k0, sA + stage * A_TILE + (wave * A_CH + i) * 128);
+#pragma unroll
+    for (int i = 0; i < B_CH; i++) dma16(srcB[i] + k0, sB + stage * B_TILE + (wave * B_CH + i) * 128);
   };
 
   /* fragment read offsets (doubles) within a stage: row*16 + ((slot ^ sw)*2 + (k&1)) */
@@ -272,14 +282,16 @@ gemm_minus_dma_nt_kernel(GemmArgs g)
   if (nsteps > 1) issue(1, GT_BK);
 
   for (size_t s = 0; s < nsteps; s++) {
-    /* stage s has landed once at most the 8 DMAs of stage s+1 are still outstanding */
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    /* stage s has landed once at most the DMAs of stage s+1 are still outstanding */
+    if (s + 1 < nsteps) {
+      if (A_CH + B_CH == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (s + 2 < nsteps) issue((int)((s + 2) % DM_STAGES), (s + 2) * GT_BK);   /* ring slot read at step s-1 */
-    const double *a_base = sA + (s % DM_STAGES) * DM_TILE + arow;
-    const double *b_base = sB + (s % DM_STAGES) * DM_TILE + brow;
+    const double *a_base = sA + (s % DM_STAGES) * A_TILE + arow;
+    const double *b_base = sB + (s % DM_STAGES) * B_TILE + brow;
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
       double af[4], bf[4];
@@ -418,13 +430,34 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   }
   static const bool no_dma = getenv("GSL_SINTERP_NO_DMA_GEMM") && getenv("GSL_SINTERP_NO_DMA_GEMM")[0] == '1';
   if (full && !b_is_kn && k >= 4 * GT_BK && !no_dma) {
-    const size_t lds = 2 * DM_STAGES * DM_TILE * sizeof(double);     /* 96 KiB */
+    static const bool no_w8 = getenv("GSL_SINTERP_NO_GEMM8") && getenv("GSL_SINTERP_NO_GEMM8")[0] == '1';
+    /* 256x128 tiles (8 waves) when the rows split evenly and there is enough work for every CU */
+    const bool w8 = !no_w8 && (m % 256 == 0) && (!lower_only || (g.tiles_n % 2) == 0) && grid >= 1024;
+    if (w8) {
+      GemmArgs h = g;
+      h.tiles_m = (int)(m / 256);
+      unsigned grid8 = (unsigned)h.tiles_m * (unsigned)h.tiles_n;
+      if (lower_only) {
+        const unsigned fr_ = (unsigned)h.tiles_n / 2;
+        grid8 = 2 * fr_ * (fr_ + 1) / 2 + ((unsigned)h.tiles_m - fr_) * (unsigned)h.tiles_n;
+      }
+      const size_t lds8 = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);   /* 144 KiB */
+      static bool attr8 = false;
+      if (!attr8) {
+        HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_dma_nt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+        attr8 = true;
+      }
+      hipLaunchKernelGGL(gemm_minus_dma_nt_kernel<4>, dim3(grid8), dim3(512), lds8, ctx->stream, h);
+      LAUNCH_CHECK(ctx);
+      return ST_SUCCESS;
+    }
+    const size_t lds = (size_t)DM_STAGES * (128 + 128) * GT_BK * sizeof(double);     /* 96 KiB */
     static bool attr_set = false;
     if (!attr_set) {
-      HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_dma_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_dma_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_minus_dma_nt_kernel, dim3(grid), dim3(256), lds, ctx->stream, g);
+    hipLaunchKernelGGL(gemm_minus_dma_nt_kernel<2>, dim3(grid), dim3(256), lds, ctx->stream, g);
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }

@@ -114,3 +114,31 @@ def test_lu_singular_reports_edom(pkg):
     d_a, d_p, d_x = dev(a), torch.zeros(4, dtype=torch.int32, device="cuda"), dev(np.ones(4))
     ctx.lu_decomp(4, ptr(d_a), 4, ptr(d_p))
     assert ctx.lu_svx(4, ptr(d_a), 4, ptr(d_p), ptr(d_x)) == pkg.capi.GSL_EDOM     # lu.c:181-184
+
+
+@pytest.mark.parametrize("m,n,k,kn,lower", [
+    (4096, 4096, 64, 0, 0), (4096, 4096, 64, 0, 1),      # 1024 tiles: 256x128 8-wave direct-to-LDS kernel
+    (6144, 2048, 80, 0, 1),                                # lower trapezoid (rows below the square part)
+    (1024, 1024, 128, 0, 1), (1024, 768, 128, 0, 0),      # 128x128 4-wave direct-to-LDS kernel
+    (4000, 64, 64, 0, 1), (777, 32, 32, 0, 1),            # single-shot small-K kernel, ragged rows
+    (300, 200, 50, 0, 0), (300, 200, 50, 1, 0), (515, 515, 33, 0, 1),   # guarded register-staged kernel
+])
+def test_gemm_building_block(pkg, m, n, k, kn, lower):
+    """C -= A op(B) on fp64 MFMA vs numpy, for every kernel variant behind gsl_sinterp_hip_gemm_minus."""
+    rng = np.random.default_rng(m + n + k)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((k, n) if kn else (n, k))
+    Cm = rng.standard_normal((m, n))
+    ctx = pkg.HipContext.on_torch_stream(0)
+    dA, dB, dC = dev(A), dev(B), dev(Cm)
+    ctx.gemm_minus(m, n, k, ptr(dA), k, ptr(dB), B.shape[1], kn, ptr(dC), n, lower)
+    ctx.sync()
+    got = dC.cpu().numpy()
+    want = Cm - (A @ B if kn else A @ B.T)
+    if lower:
+        rows, cols = np.indices((m, n))
+        mask = cols <= rows
+        assert np.abs(got - want)[mask].max() <= 1e-12 * k
+        assert np.array_equal(got[~mask], Cm[~mask])          # strict upper part untouched
+    else:
+        assert np.abs(got - want).max() <= 1e-12 * k
