@@ -195,7 +195,12 @@ def main():
                        "parallelism": f"target shards x{world}, weights broadcast (RCCL)" if world > 1 else "1 GPU"},
             "phase_ms": {k: round(v, 4) for k, v in ph_ms.items()},
         }
-        out.update(rooflines(cfg, n, dim, m_rank, ph_ms, dominant, extra))
+        gemm = time_top_gemm(pkg, ctx, n) if cfg["kind"] != "bary" else None
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (not live)
+            pmc = json.load(open(pmc_path)).get(args.config, {})
+        out.update(rooflines(cfg, n, dim, m_rank, ph_ms, dominant, extra, gemm, pmc))
         out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, n, dim)
@@ -204,34 +209,62 @@ def main():
         dist.destroy_process_group()
 
 
-def rooflines(cfg, n, dim, m_rank, ph, dominant, extra=None):
+def time_top_gemm(pkg, ctx, n, reps=3):
+    """HIP-event timing of ONE launch of the factorisation's dominant kernel: the top-level
+    trailing update of the recursive Cholesky, C[n/2 x n/2] -= A A^T (lower part), K = n/2."""
+    import torch
+    h = (n // 2 // 128) * 128
+    if h < 256:
+        return None
+    a = torch.randn((h, h), dtype=torch.float64, device="cuda")
+    c = torch.randn((h, h), dtype=torch.float64, device="cuda")
+    ctx.gemm_minus(h, h, h, a.data_ptr(), h, a.data_ptr(), h, 0, c.data_ptr(), h, 1)
+    ctx.timer_start()
+    for _ in range(reps):
+        ctx.gemm_minus(h, h, h, a.data_ptr(), h, a.data_ptr(), h, 0, c.data_ptr(), h, 1)
+    ms = ctx.timer_stop() / reps
+    tiles = h // 128
+    flops = 2.0 * 128 * 128 * h * (tiles * (tiles + 1) // 2)        # launched (lower-trapezoid) tiles only
+    return {"h": h, "ms": ms, "tflops": flops / ms / 1e9}
+
+
+def rooflines(cfg, n, dim, m_rank, ph, dominant, extra=None, gemm=None, pmc=None):
     """Roofline objects from live HIP-event timings.  Algorithmic work per SURVEY.md 8(d)."""
     res = {}
+    pmc = pmc or {}
     if cfg["kind"] == "bary":
         t = ph["bary_eval"] * 1e-3
         by = 28.0 * m_rank                               # 16 B target in, 8 B value + 4 B leaf out
-        res["roofline"] = {"kernel": "bary_eval_kernel", "bound": "hbm", "achieved": round(by / t / 1e9, 3),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 6),
-                           "traffic": None,
-                           "note": "latency-bound DAG walk (~65 dependent 64-B gathers per target); "
-                                   "algorithmic bytes = 28 B/target"}
+        res["roofline"] = {"kernel": "bary_eval_kernel (+ cell sort of the targets)", "bound": "hbm",
+                           "achieved": round(by / t / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 6), "traffic": pmc.get("bary_eval_kernel"),
+                           "note": "latency-bound DAG walk (~65 dependent 64-B gathers per target, DAG resident in "
+                                   "Infinity Cache); algorithmic bytes = 28 B/target"}
         return res
     route = (extra or {}).get("route", {}).get("route", 1)
     flops = 2.0 * n ** 3 / 3.0 if route == 3 else (n ** 3) / 3.0      # LU vs Cholesky factorisation
     tf = ph["init"] * 1e-3
     te = ph["eval"] * 1e-3
     by = (8.0 * dim + 8.0) * m_rank
-    r_factor = {"kernel": "init = fill + factorisation (gemm_minus_kernel on fp64 MFMA + panel kernels) + sweeps",
-                "bound": "mfma", "achieved": round(flops / tf / 1e12, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(flops / tf / 1e12 / FP64_PEAK_TFLOPS, 5), "traffic": None,
-                "route": {1: "cholesky", 2: "shifted-SPD cholesky + Woodbury", 3: "pivoted LU"}.get(route, "?")}
+    r_gemm = None
+    if gemm:
+        r_gemm = {"kernel": "gemm_minus_dma_nt_kernel (top-level trailing update, %d^3 lower)" % gemm["h"],
+                  "bound": "mfma", "achieved": round(gemm["tflops"], 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(gemm["tflops"] / FP64_PEAK_TFLOPS, 5), "launch_ms": round(gemm["ms"], 4),
+                  "traffic": pmc.get("gemm_minus_dma_nt_kernel")}
     pair_ops = n * m_rank
     r_eval = {"kernel": "rbf_eval_kernel", "bound": "hbm", "achieved": round(by / te / 1e9, 3), "peak": HBM_PEAK_GBS,
-              "unit": "GB/s", "frac": round(by / te / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+              "unit": "GB/s", "frac": round(by / te / 1e9 / HBM_PEAK_GBS, 6), "traffic": pmc.get("rbf_eval_kernel"),
               "pair_evals_per_s": round(pair_ops / te, 1),
-              "note": "compute-bound by construction (N pair-evals per 8d+8 B); see pair_evals_per_s vs fp64-VALU peak"}
-    res["roofline"] = r_factor if tf >= te else r_eval
-    res["roofline_other"] = r_eval if tf >= te else r_factor
+              "note": "fp64-VALU bound by construction (N pair-evals per 8d+8 B): the HBM fraction is ~1e-3; "
+                      "pair_evals_per_s is the meaningful rate"}
+    # dominant single kernel: the GEMM when the factorisation (mostly GEMM) outweighs the sweep
+    gemm_dominant = r_gemm is not None and 0.55 * tf > te
+    res["roofline"] = r_gemm if gemm_dominant else r_eval
+    res["roofline_other"] = r_eval if gemm_dominant else r_gemm
+    res["init_as_a_unit"] = {"flops": flops, "tflops": round(flops / tf / 1e12, 4),
+                             "frac_of_fp64_mfma_peak": round(flops / tf / 1e12 / FP64_PEAK_TFLOPS, 5),
+                             "route": {1: "cholesky", 2: "shifted-SPD cholesky + Woodbury", 3: "pivoted LU"}.get(route, "?")}
     res["solve_gflops"] = round(flops / tf / 1e9, 2)
     res["eval_only_mpts"] = round(m_rank / te / 1e6, 3)
     return res
