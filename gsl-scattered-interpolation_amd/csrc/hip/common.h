@@ -37,6 +37,10 @@ struct gsl_sinterp_hip_ctx {
   hipStream_t la_stream[16];
   hipEvent_t la_event[4096];
   int la_events_made, la_events_used, use_lookahead;
+  /* stream-K GEMM (gemm.hip): one partial-tile slot + one flag per persistent workgroup */
+  double *d_sk_partial;
+  unsigned *d_sk_flags;
+  int sk_wgs;               /* persistent workgroups = CUs of the device; 0 = not prepared */
   char err[512];
 };
 
@@ -81,6 +85,11 @@ int sinterp_workspace(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
    lower_only: C is square on the diagonal, tiles strictly above it are skipped */
 int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, const double *A, size_t lda,
                        const double *B, size_t ldb, int b_is_kn, double *C, size_t ldc, int lower_only);
+
+/* allocates the stream-K buffers of the context; must be called OUTSIDE stream capture (the
+   factorisation drivers call it before they start capturing).  Without it the GEMM falls back to
+   the one-tile-per-workgroup kernels. */
+int sinterp_streamk_prepare(gsl_sinterp_hip_ctx *ctx);
 
 /* blocked triangular sweeps (chol.hip): the block being solved is read from b and
    written to xout (b != xout), the remaining right-hand side is updated in b.

@@ -76,6 +76,8 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->d_inv) (void)hipFree(ctx->d_inv);
   if (ctx->d_sort) (void)hipFree(ctx->d_sort);
+  if (ctx->d_sk_partial) (void)hipFree(ctx->d_sk_partial);
+  if (ctx->d_sk_flags) (void)hipFree(ctx->d_sk_flags);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

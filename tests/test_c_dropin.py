@@ -1,0 +1,16 @@
+"""Compile a plain C program against include/gsl_sinterp.h + libgsl_sinterp.so (what a user of the
+reference does with linear_simplex.h) and check the reference's known answers from C."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_program_links_and_reproduces_known_answers(pkg, tmp_path):
+    libdir = os.path.dirname(pkg.library_path())
+    exe = str(tmp_path / "dropin")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "dropin_known_answers.c"), "-o", exe,
+                           "-L", libdir, "-lgsl_sinterp", "-lm", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "weather_stations.csv")], text=True)
+    assert "ok" in out

@@ -145,3 +145,24 @@ def test_lowlevel_pack_matches_host_records(pkg, orc):
     ovals, oleaf = o.eval_many(x, f, y)
     assert outside == 0
     assert np.array_equal(d_l.cpu().numpy(), oleaf) and np.array_equal(bits(d_v.cpu().numpy()), bits(ovals))
+
+
+def test_facade_linear_simplex(pkg, orc):
+    """gsl_sinterp alloc/init/eval_many/eval_e with the linear-simplex type == oracle, bit for bit."""
+    n, m = 3000, 20000
+    x = orc.synth_centres(n, 2)
+    f = orc.synth_response(x)
+    y = orc.synth_targets(0, m, 2)
+    s = pkg.Sinterp("linear_simplex", 2, n, 0)
+    assert s.name() == "linear-simplex"
+    assert s.set_tree_options(0, pkg.capi.Rng(0)) == 0
+    assert s.init(x, f) == 0
+    st, vals, leaf = s.eval_many(y, want_leaf=True)
+    o = orc.Tree(2, n)
+    assert o.init(x, flags=0, seed=0) == 0
+    ovals, oleaf = o.eval_many(x, f, y)
+    assert st == 0 and np.array_equal(leaf, oleaf) and np.array_equal(bits(vals), bits(ovals))
+    st, v = s.eval_e(y[7])
+    assert st == 0 and np.float64(v).view(np.uint64) == bits(ovals[7:8])[0]
+    st, v = s.eval_e([1e12, 0.0])
+    assert st == pkg.capi.GSL_EDOM and np.isnan(v)       # like gsl_interp_eval_e outside [xmin, xmax]
