@@ -248,10 +248,10 @@ def rooflines(cfg, n, dim, m_rank, ph, dominant, extra=None, gemm=None, pmc=None
     by = (8.0 * dim + 8.0) * m_rank
     r_gemm = None
     if gemm:
-        r_gemm = {"kernel": "gemm_minus_dma_nt_kernel (top-level trailing update, %d^3 lower)" % gemm["h"],
+        r_gemm = {"kernel": "gemm_minus_streamk_kernel (top-level trailing update, %d^3 lower)" % gemm["h"],
                   "bound": "mfma", "achieved": round(gemm["tflops"], 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(gemm["tflops"] / FP64_PEAK_TFLOPS, 5), "launch_ms": round(gemm["ms"], 4),
-                  "traffic": pmc.get("gemm_minus_dma_nt_kernel")}
+                  "traffic": pmc.get("gemm_minus_streamk_kernel")}
     pair_ops = n * m_rank
     r_eval = {"kernel": "rbf_eval_kernel", "bound": "hbm", "achieved": round(by / te / 1e9, 3), "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": round(by / te / 1e9 / HBM_PEAK_GBS, 6), "traffic": pmc.get("rbf_eval_kernel"),

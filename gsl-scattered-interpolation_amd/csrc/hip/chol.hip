@@ -238,6 +238,8 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
   void *d_diag = NULL;
   int st = sinterp_workspace(ctx, nblk * CB * CB * sizeof(double), &d_diag);
   if (st) return st;
+  st = sinterp_streamk_prepare(ctx);
+  if (st) return st;
   int replayed = 0;
   st = sinterp_graph_try_launch(ctx, 0, n, lda, d_a, NULL, &replayed);
   if (st) return st;

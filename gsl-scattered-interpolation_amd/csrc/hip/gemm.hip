@@ -325,6 +325,232 @@ gemm_minus_dma_nt_kernel(GemmArgs g)
 }
 
 /* ------------------------------------------------------------------------ */
+/* Stream-K form of the DMA kernel.  With one workgroup per tile the launch time is quantised in
+   whole tiles per CU: 8192^2 lower / 256x128 tiles = 1056 tiles = 4.1 rounds on 256 CUs (a fifth,
+   almost empty round costs 20 %), 2048^2 lower = 136 tiles of 128x128 leaves 120 CUs idle.  Here
+   the launch is G persistent workgroups (G <= #CUs) and the unit of work is one K-step of one
+   tile: workgroup w owns the contiguous range [total*w/G, total*(w+1)/G) of the (tile, K-step)
+   space, so every CU gets the same number of MFMA steps whatever the tile count.
+   A tile whose K range is cut is finished by the workgroup holding its FIRST K-step (the owner);
+   the others store their accumulators to their private slot and raise a flag.  A non-owner
+   segment is always the first thing its workgroup does, so the owner (which reaches the tile
+   last) finds the flags already set and never waits on a workgroup that itself waits.  Partials
+   are added in ascending workgroup order: the summation order is a pure function of the shape,
+   results are reproducible run to run.
+   Partials and flags are exchanged with agent-scope atomic loads/stores (sc1: coherent across
+   the 8 XCD L2s) and an explicit vmcnt(0) + barrier before the flag, so no L2 writeback /
+   invalidate is needed.  The owner clears the flag it consumed: launches on one stream are
+   serialised, so the buffers are reusable by the next launch (and by a hipGraph replay). */
+struct StreamK {
+  unsigned steps;               /* K-steps per tile */
+  unsigned total;               /* tiles * steps */
+  unsigned base, rem;           /* total = G*base + rem: workgroup w starts at w*base + min(w, rem) */
+  double *partial;              /* [G][BM*128] */
+  unsigned *flags;              /* [G] */
+};
+
+template <int BM>
+__device__ __forceinline__ void decode_tile(const GemmArgs &g, unsigned tile, int &tm, int &tn)
+{
+  if (!g.lower_only) {
+    tm = (int)(tile / g.tiles_n); tn = (int)(tile % g.tiles_n);
+  } else {
+    constexpr unsigned R = BM / GT_BN;
+    const unsigned full_rows = (unsigned)g.tiles_n / R;
+    const unsigned tri = R * full_rows * (full_rows + 1) / 2;
+    if (tile < tri) {
+      const double t = (double)tile / (double)R;
+      tm = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+      while (R * (unsigned)(tm + 1) * (unsigned)(tm + 2) / 2 <= tile) tm++;
+      while (R * (unsigned)tm * (unsigned)(tm + 1) / 2 > tile) tm--;
+      tn = (int)(tile - R * (unsigned)tm * (unsigned)(tm + 1) / 2);
+    } else {
+      const unsigned t2 = tile - tri;
+      tm = (int)full_rows + (int)(t2 / g.tiles_n); tn = (int)(t2 % g.tiles_n);
+    }
+  }
+}
+
+template <int WR>
+__global__ void __launch_bounds__(128 * WR, 1)
+gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
+{
+  constexpr int BM = 64 * WR;
+  constexpr int NW = 2 * WR;
+  constexpr int NT = 128 * WR;                          /* threads */
+  constexpr int A_TILE = BM * GT_BK, B_TILE = GT_BN * GT_BK;
+  constexpr int A_CH = BM / 8 / NW, B_CH = (GT_BN / 8) / NW;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *sA = smem;
+  double *sB = smem + DM_STAGES * A_TILE;
+
+  const unsigned G = gridDim.x, bid = blockIdx.x;
+  const unsigned q = G / 8, r = G % 8, xcd = bid % 8;
+  const unsigned gl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;   /* XCD-contiguous ranges */
+  auto start_of = [&](unsigned w) -> unsigned { return w * x.base + (w < x.rem ? w : x.rem); };
+  unsigned it = __builtin_amdgcn_readfirstlane(start_of(gl));
+  const unsigned it_end = __builtin_amdgcn_readfirstlane(start_of(gl + 1));
+  unsigned tile = __builtin_amdgcn_readfirstlane(it / x.steps);
+
+  while (it < it_end) {
+    const unsigned tile_first = tile * x.steps, tile_end = tile_first + x.steps;
+    const unsigned s0 = it - tile_first;
+    const unsigned s1 = it_end < tile_end ? it_end - tile_first : x.steps;
+    int tm, tn;
+    decode_tile<BM>(g, tile, tm, tn);
+    const size_t row0 = (size_t)tm * BM, col0 = (size_t)tn * GT_BN;
+
+    double4_t acc[4][4];
+    {
+      /* Everything lane-dependent is derived from a laundered thread id INSIDE the segment: left to
+         itself the compiler hoists it all out of the while loop, runs out of VGPRs (the 8-wave
+         variant has 256 including the 128 accumulators) and spills operands of the K loop -- and
+         a scratch reload's s_waitcnt vmcnt(0) also drains the DMA ring. */
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, wave = tid >> 6;
+      const int wr = wave >> 1, wc = wave & 1;
+      const int fr = lane & 15, fq = lane >> 4;
+      const int sw = (fr >> 1) & 7;
+      int koff[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) koff[kk] = (((kk * 2 + (fq >> 1)) ^ sw) << 1) + (fq & 1);
+      const int arow = (wr * 64 + fr) * GT_BK, brow = (wc * 64 + fr) * GT_BK;
+
+      const double *srcA[A_CH], *srcB[B_CH];
+#pragma unroll
+      for (int i = 0; i < A_CH; i++) {
+        const int rr = (wave * A_CH + i) * 8 + (lane >> 3);
+        srcA[i] = g.A + (row0 + rr) * g.lda + (((lane & 7) ^ ((rr >> 1) & 7)) << 1);
+      }
+#pragma unroll
+      for (int i = 0; i < B_CH; i++) {
+        const int rr = (wave * B_CH + i) * 8 + (lane >> 3);
+        srcB[i] = g.B + (col0 + rr) * g.ldb + (((lane & 7) ^ ((rr >> 1) & 7)) << 1);
+      }
+      auto issue = [&](int stage, size_t k0) {
+#pragma unroll
+        for (int i = 0; i < A_CH; i++) dma16(srcA[i] + k0, sA + stage * A_TILE + (wave * A_CH + i) * 128);
+#pragma unroll
+        for (int i = 0; i < B_CH; i++) dma16(srcB[i] + k0, sB + stage * B_TILE + (wave * B_CH + i) * 128);
+      };
+
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+      __syncthreads();                                   /* the ring is free: previous segment fully read */
+      issue(0, (size_t)s0 * GT_BK);
+      if (s0 + 1 < s1) issue(1, (size_t)(s0 + 1) * GT_BK);
+      for (unsigned s = s0; s < s1; s++) {
+        const unsigned rel = s - s0;
+        if (s + 1 < s1) {
+          if (A_CH + B_CH == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < s1) issue((int)((rel + 2) % DM_STAGES), (size_t)(s + 2) * GT_BK);
+        const double *a_base = sA + (rel % DM_STAGES) * A_TILE + arow;
+        const double *b_base = sB + (rel % DM_STAGES) * B_TILE + brow;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          double af[4], bf[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) af[i] = a_base[i * 16 * GT_BK + koff[kk]];
+#pragma unroll
+          for (int j = 0; j < 4; j++) bf[j] = b_base[j * 16 * GT_BK + koff[kk]];
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+
+    /* epilogue: its own laundered copies, so nothing of it is live across the K loop */
+    int tid = threadIdx.x;
+    size_t row0e = row0, col0e = col0;
+    asm volatile("" : "+v"(tid), "+s"(row0e), "+s"(col0e));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    if (s0 != 0) {
+      /* not the owner: publish the partial tile */
+      double *pp = x.partial + (size_t)gl * (BM * GT_BN) + tid;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++)
+            __hip_atomic_store(pp + ((i * 4 + j) * 4 + rg) * NT, acc[i][j][rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(x.flags + gl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (s1 < x.steps) {
+        for (unsigned w = gl + 1; w < G; w++) {
+          if (start_of(w) >= tile_end) break;
+          if (tid == 0)
+            while (__hip_atomic_load(x.flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+          __syncthreads();
+          const double *pp = x.partial + (size_t)w * (BM * GT_BN) + tid;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+              for (int rg = 0; rg < 4; rg++)
+                acc[i][j][rg] += __hip_atomic_load(pp + ((i * 4 + j) * 4 + rg) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_sched_barrier(0);            /* 16 loads in flight at a time */
+          }
+          if (tid == 0) __hip_atomic_store(x.flags + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const size_t gcol = col0e + wc * 64 + j * 16 + fr;
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const size_t grow = row0e + wr * 64 + i * 16 + fq + 4 * rg;
+            if (!g.lower_only || gcol <= grow) {
+              double *p = g.C + grow * g.ldc + gcol;
+              *p = *p - acc[i][j][rg];
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    it = tile_first + s1;
+    tile++;
+  }
+}
+
+int sinterp_streamk_prepare(gsl_sinterp_hip_ctx *ctx)
+{
+  if (ctx->sk_wgs) return ST_SUCCESS;
+  static const bool off = getenv("GSL_SINTERP_NO_STREAMK") && getenv("GSL_SINTERP_NO_STREAMK")[0] == '1';
+  if (off) return ST_SUCCESS;
+  int cus = 0;
+  HIP_OK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+  if (cus <= 0) return ST_SUCCESS;
+  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_partial, (size_t)cus * 256 * GT_BN * sizeof(double)));
+  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_flags, (size_t)cus * sizeof(unsigned)));
+  HIP_OK(ctx, hipMemset(ctx->d_sk_flags, 0, (size_t)cus * sizeof(unsigned)));
+  HIP_OK(ctx, hipDeviceSynchronize());
+  ctx->sk_wgs = cus;
+  return ST_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Small-K, skinny-N update (the K = 32 / 64 levels of the recursions): C[m x BN] -= A[m x K] B^T,
    B stored [BN][K], K <= 64.  Everything a workgroup needs -- its 128 x K slice of A, all of B and
    its C tile -- is fetched in ONE global round trip; the A slice is negated on its way into LDS
@@ -431,6 +657,45 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   static const bool no_dma = getenv("GSL_SINTERP_NO_DMA_GEMM") && getenv("GSL_SINTERP_NO_DMA_GEMM")[0] == '1';
   if (full && !b_is_kn && k >= 4 * GT_BK && !no_dma) {
     static const bool no_w8 = getenv("GSL_SINTERP_NO_GEMM8") && getenv("GSL_SINTERP_NO_GEMM8")[0] == '1';
+    if (ctx->sk_wgs > 0 && !ctx->use_lookahead) {
+      /* stream-K: G persistent workgroups share the (tile, K-step) space evenly */
+      StreamK x;
+      x.steps = (unsigned)(k / GT_BK);
+      x.partial = ctx->d_sk_partial; x.flags = ctx->d_sk_flags;
+      GemmArgs h = g;
+      unsigned tiles = grid;
+      bool w8 = !no_w8 && (m % 256 == 0) && (!lower_only || (g.tiles_n % 2) == 0);
+      if (w8) {
+        h.tiles_m = (int)(m / 256);
+        tiles = (unsigned)h.tiles_m * (unsigned)h.tiles_n;
+        if (lower_only) {
+          const unsigned fr_ = (unsigned)h.tiles_n / 2;
+          tiles = 2 * fr_ * (fr_ + 1) / 2 + ((unsigned)h.tiles_m - fr_) * (unsigned)h.tiles_n;
+        }
+        /* the big tile only pays when every CU gets a few K-steps of it */
+        if ((unsigned long long)tiles * x.steps < 16ull * (unsigned)ctx->sk_wgs) { w8 = false; h = g; tiles = grid; }
+      }
+      const unsigned long long total64 = (unsigned long long)tiles * x.steps;
+      unsigned long long want = total64 / 16;            /* >= 16 K-steps per workgroup ... */
+      if (want < tiles) want = tiles;                     /* ... but never fewer workgroups than tiles */
+      if (want > (unsigned long long)ctx->sk_wgs) want = (unsigned long long)ctx->sk_wgs;
+      const unsigned G = (unsigned)(want ? want : 1);
+      if (total64 < 0x7fffffffull) {
+      x.total = (unsigned)total64; x.base = x.total / G; x.rem = x.total % G;
+      static bool attr_sk2 = false, attr_sk4 = false;
+      if (w8) {
+        const size_t lds8 = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);
+        if (!attr_sk4) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8)); attr_sk4 = true; }
+        hipLaunchKernelGGL(gemm_minus_streamk_kernel<4>, dim3(G), dim3(512), lds8, ctx->stream, h, x);
+      } else {
+        const size_t lds4 = (size_t)DM_STAGES * (128 + 128) * GT_BK * sizeof(double);
+        if (!attr_sk2) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); attr_sk2 = true; }
+        hipLaunchKernelGGL(gemm_minus_streamk_kernel<2>, dim3(G), dim3(256), lds4, ctx->stream, h, x);
+      }
+      LAUNCH_CHECK(ctx);
+      return ST_SUCCESS;
+      }
+    }
     /* 256x128 tiles (8 waves) when the rows split evenly and there is enough work for every CU */
     const bool w8 = !no_w8 && (m % 256 == 0) && (!lower_only || (g.tiles_n % 2) == 0) && grid >= 1024;
     if (w8) {
@@ -479,5 +744,7 @@ extern "C" int gsl_sinterp_hip_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, si
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   REQUIRE(ctx, lda >= k && ldc >= n && ldb >= (b_is_kn ? n : k), ST_EINVAL);
   REQUIRE(ctx, (m == 0 || n == 0 || k == 0) || (d_a && d_b && d_c), ST_EFAULT);
+  int st = sinterp_streamk_prepare(ctx);
+  if (st) return st;
   return sinterp_gemm_minus(ctx, m, n, k, d_a, lda, d_b, ldb, b_is_kn, d_c, ldc, lower_only);
 }

@@ -122,6 +122,8 @@ def test_lu_singular_reports_edom(pkg):
     (1024, 1024, 128, 0, 1), (1024, 768, 128, 0, 0),      # 128x128 4-wave direct-to-LDS kernel
     (4000, 64, 64, 0, 1), (777, 32, 32, 0, 1),            # single-shot small-K kernel, ragged rows
     (300, 200, 50, 0, 0), (300, 200, 50, 1, 0), (515, 515, 33, 0, 1),   # guarded register-staged kernel
+    (1024, 1024, 512, 0, 1), (2304, 384, 1024, 0, 0),    # stream-K, 4-wave: tiles cut in 2 / 4 K-ranges
+    (2048, 2048, 2048, 0, 1), (2048, 1024, 1536, 0, 0),  # stream-K, 8-wave: several contributors per tile
 ])
 def test_gemm_building_block(pkg, m, n, k, kn, lower):
     """C -= A op(B) on fp64 MFMA vs numpy, for every kernel variant behind gsl_sinterp_hip_gemm_minus."""
@@ -142,3 +144,24 @@ def test_gemm_building_block(pkg, m, n, k, kn, lower):
         assert np.array_equal(got[~mask], Cm[~mask])          # strict upper part untouched
     else:
         assert np.abs(got - want).max() <= 1e-12 * k
+
+
+@pytest.mark.gpu
+def test_gemm_stream_k_is_reproducible(pkg):
+    """The stream-K split points and the order partial tiles are added in are functions of the shape
+    only: repeated launches (which also re-use the flag / partial buffers) give identical bits."""
+    m, n, k = 2048, 2048, 1024
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((m, k)); Cm = rng.standard_normal((m, n))
+    ctx = pkg.HipContext.on_torch_stream(0)
+    dA = dev(A)
+    outs = []
+    for _ in range(3):
+        dC = dev(Cm)
+        ctx.gemm_minus(m, n, k, ptr(dA), k, ptr(dA), k, 0, ptr(dC), n, 1)
+        ctx.sync()
+        outs.append(dC.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    want = Cm - A @ A.T
+    rows, cols = np.indices((m, n))
+    assert np.abs(outs[0] - want)[cols <= rows].max() <= 1e-12 * k

@@ -28,7 +28,9 @@ def run(m, n, k, kn, lower, reps=5):
     fl = 2.0 * m * n * k * (0.5 * (1 + 128.0 / n) if lower else 1.0)
     print(f"m={m} n={n} k={k} {'KN' if kn else 'NT'} lower={lower}: {ms:.3f} ms  {fl/ms/1e9:.2f} TF  err={err:.2e}", flush=True)
 import sys as _s
-shapes = [(2048, 2048, 2048, 0, 0), (2048, 2048, 2048, 0, 1), (1024, 256, 512, 0, 0), (4096, 4096, 4096, 0, 0), (8192, 8192, 8192, 0, 1),
-          (8192, 8192, 8192, 0, 0), (16128, 256, 256, 0, 1), (12288, 4096, 4096, 0, 1)]
+shapes = [(2048, 2048, 2048, 0, 0), (2048, 2048, 2048, 0, 1), (1024, 1024, 1024, 0, 1), (3072, 1024, 1024, 0, 1),
+          (1024, 256, 512, 0, 0), (4096, 4096, 4096, 0, 0), (4096, 4096, 4096, 0, 1),
+          (8192, 8192, 8192, 0, 1), (8192, 8192, 8192, 0, 0), (16128, 256, 256, 0, 1), (8192, 128, 128, 0, 1),
+          (12288, 4096, 4096, 0, 1), (14336, 2048, 2048, 0, 1), (15360, 1024, 1024, 0, 1), (8192, 512, 512, 0, 1)]
 for args in shapes:
     run(*args, reps=3)
