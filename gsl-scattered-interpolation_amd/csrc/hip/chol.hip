@@ -20,6 +20,7 @@
  */
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define CB 32 /* base panel width */
 
@@ -131,6 +132,334 @@ chol_diag_writeback_kernel(double *__restrict__ A, size_t lda, size_t n, const d
   }
 }
 
+/* ------------------------------------------------------------------------ */
+/* 128-wide panels: two launches per panel instead of the 4 base + 3 small-K launches of the
+   32-wide recursion.
+     chol_diag128_kernel  (one workgroup): factors the 128x128 diagonal block in LDS -- four
+        32-wide steps of {single-wave potrf32 on registers, row-per-thread TRSM, MFMA trailing
+        update} -- writes L in place and the inverses of its four 32x32 diagonal blocks (forward
+        substitution, overlapped with the TRSM phase) to a side buffer;
+     chol_trsm128_kernel  (64 rows per workgroup, 16 per wave): X = B L^-T by block substitution,
+        every step an MFMA product:  X_c = (B_c - sum_{p<c} X_p L_cp^T) Dinv_c^T,  c = 0..3,
+        B tile, the off-diagonal blocks of L and the Dinv blocks staged in LDS.
+   Multiplying by explicitly inverted 32x32 diagonal blocks of a Cholesky factor is the standard
+   GPU formulation of the panel TRSM (the sweeps further down do the same with 64x64 blocks).
+   LDS layout of triangles: packed 32x32 blocks of pitch 34 doubles -- 34 = 2 mod 4 makes the
+   (row = lane&15, k = lane>>4) MFMA fragment reads conflict free. */
+typedef double double4_t __attribute__((ext_vector_type(4)));
+#define PB 128
+#define PQ 34
+#define PBLK (32 * PQ)
+#define TR_LD 130     /* pitch of the 64 x 128 tile of the trsm kernel (= 2 mod 4) */
+
+__device__ __forceinline__ int pblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * PBLK; }
+
+/* 16x16 fragment (fi, fj) of  acc += sgn * A * B^T,  A and B row-major [32][PQ] blocks, K = 32 */
+__device__ __forceinline__ double4_t frag_nt(const double *Ab, const double *Bb, int fi, int fj, int lane, double4_t acc, double sgn)
+{
+  const double *ap = Ab + (fi * 16 + (lane & 15)) * PQ + (lane >> 4);
+  const double *bp = Bb + (fj * 16 + (lane & 15)) * PQ + (lane >> 4);
+#pragma unroll
+  for (int kk = 0; kk < 8; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * ap[kk * 4], bp[kk * 4], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ double4_t frag_load(const double *Cb, int fi, int fj, int lane)
+{
+  double4_t c;
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) c[rg] = Cb[(fi * 16 + (lane >> 4) + 4 * rg) * PQ + fj * 16 + (lane & 15)];
+  return c;
+}
+__device__ __forceinline__ void frag_store(double *Cb, int fi, int fj, int lane, double4_t c)
+{
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) Cb[(fi * 16 + (lane >> 4) + 4 * rg) * PQ + fj * 16 + (lane & 15)] = c[rg];
+}
+
+/* potrf32 on one wave: lane = row, the row's 32 entries in registers, left-looking; compile-time
+   recursion over the columns (straight-line code, no branch per column: a failing pivot is recorded
+   and reported once at the end).
+   Column J+1 of row i is  a_i[J+1] - sum_{k<=J} L[i][k] L[J+1][k].  Row J+1 of L has to reach every
+   lane: a readlane pair per entry (the obvious way) makes the kernel issue bound.  Instead every
+   finished column is stored to the LDS image of the block (one ds_write_b64 per column), and row
+   J+1's entries k < J -- final before column J starts -- come back as uniform-address ds_read_b128
+   (two entries per instruction), issued before column J's rsq chain and consumed in its latency
+   shadow (a wave issues in order: the FMAs are interleaved by hand between the ~8 dependent chain
+   ops, sched_barrier pins the order; measured dependent-issue latency of v_fma_f64 is ~16 cycles).  Only the k = J term needs a readlane. */
+template <int J, int SLOT>
+__device__ __forceinline__ void potrf32_fill(const double (&a)[CB], const double (&r)[CB], double (&p)[4])
+{
+  /* four accumulators: a dependent fp64 FMA issues every ~16 cycles, an independent one every 4 */
+  if constexpr (J + 1 < CB && SLOT >= 2) {
+#pragma unroll
+    for (int k = ((SLOT - 2) * J) / 6; k < ((SLOT - 1) * J) / 6; k++) p[k & 3] = fma(-a[k], r[k], p[k & 3]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int J>
+__device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double cur, int &badcol, double &myinv, double *D)
+{
+  if constexpr (J < CB) {
+    double v = cur;
+    if constexpr (J > 0) v = fma(-a[J - 1], lane_bcast(a[J - 1], J), v);
+    double d = lane_bcast(v, J);
+    double r[CB];
+    if constexpr (J + 1 < CB) {
+#pragma unroll
+      for (int k = 0; k < J; k += 2) {
+        const double2 t = *reinterpret_cast<const double2 *>(D + (J + 1) * PQ + k);
+        r[k] = t.x;
+        if (k + 1 < CB) r[k + 1] = t.y;
+      }
+    }
+    const bool ok = d > 0.0;                            /* cholesky.c:120-123 */
+    badcol = (!ok && badcol == 0) ? J + 1 : badcol;
+    d = ok ? d : 1.0;
+    /* 1/sqrt(d) = y0 (1 - r)^(-1/2), r = 1 - d y0^2 with the v_rsq_f64 seed y0 (|r| <~ 2^-21):
+       y0 (1 + r/2 + 3 r^2/8) is exact to r^3 ~ 1e-19 -- four dependent ops after the seed instead
+       of the seven of a Newton step plus correction.  sqrt(d) = d/sqrt(d) with one residual
+       correction, off the critical path.  Both end within an ulp or two of cholesky.c:125-126's
+       sqrt and divide. */
+    double p[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (J + 1 < CB) p[0] = a[J + 1];
+    const double y0 = __builtin_amdgcn_rsq(d);
+    potrf32_fill<J, 0>(a, r, p);
+    const double t = d * y0;
+    potrf32_fill<J, 1>(a, r, p);
+    const double rr = fma(-t, y0, 1.0);
+    potrf32_fill<J, 2>(a, r, p);
+    const double s1 = fma(0.375, rr, 0.5), u = y0 * rr;
+    potrf32_fill<J, 3>(a, r, p);
+    const double inv = fma(u, s1, y0);
+    potrf32_fill<J, 4>(a, r, p);
+    const double an = v * inv, sd0 = d * inv;
+    potrf32_fill<J, 5>(a, r, p);
+    const double sd = fma(fma(-sd0, sd0, d), 0.5 * inv, sd0);
+    potrf32_fill<J, 6>(a, r, p);
+    a[J] = (lane == J) ? sd : an;
+    myinv = (lane == J) ? inv : myinv;
+    D[lane * PQ + J] = a[J];                            /* column J of L, for the row reads of later columns */
+    potrf32_fill<J, 7>(a, r, p);
+    potrf32_cols<J + 1>(a, lane, (p[0] + p[1]) + (p[2] + p[3]), badcol, myinv, D);
+  }
+}
+
+#ifdef SINTERP_DIAG_PROF
+__device__ unsigned long long g_diag_ts[32];
+#define TSTAMP(i) do { if (threadIdx.x == 0) g_diag_ts[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int gsl_sinterp_hip_debug_diag_ts(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_ts), sizeof(unsigned long long) * 32); }
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(256)
+chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restrict__ info, double *__restrict__ diag_store,
+                    double *__restrict__ Dinvg)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *S = sm;                       /* 10 packed blocks of the lower triangle */
+  double *Dv = S + 10 * PBLK;           /* 4 blocks: inverses of the diagonal blocks */
+  double *sInv = Dv + 4 * PBLK;         /* 128 reciprocal diagonal entries */
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double *Ab = A + j0 * lda + j0;
+  TSTAMP(0);
+
+  /* load the lower triangle (whole 32x32 blocks, coalesced along k): all 40 loads of a thread are
+     issued before the first LDS store (one memory round trip, not 40) */
+  {
+    double v[40];
+    const int r8 = tid >> 5, k = tid & 31;
+#pragma unroll
+    for (int t = 0; t < 40; t++) {
+      constexpr int BI[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, BJ[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+      const int b = t >> 2, r = (t & 3) * 8 + r8;
+      v[t] = Ab[(size_t)(BI[b] * 32 + r) * lda + BJ[b] * 32 + k];
+    }
+#pragma unroll
+    for (int t = 0; t < 40; t++) S[(t >> 2) * PBLK + ((t & 3) * 8 + r8) * PQ + k] = v[t];
+  }
+  __syncthreads();
+  TSTAMP(1);
+
+  for (int jb = 0; jb < 4; jb++) {
+    double *D = S + pblk(jb, jb);
+    TSTAMP(2 + jb * 4);
+    if (wave == 0) {
+      /* potrf32 (see potrf32_cols); lanes 32..63 duplicate lanes 0..31 */
+      const int l = lane & 31;
+      double a[CB];
+#pragma unroll
+      for (int k = 0; k < CB; k++) a[k] = (k <= l) ? D[l * PQ + k] : 0.0;
+      int badcol = 0;
+      double myinv = 1.0;
+      potrf32_cols<0>(a, l, a[0], badcol, myinv, D);
+      if (lane < CB) {
+        sInv[jb * 32 + lane] = myinv;
+#pragma unroll
+        for (int k = 0; k < CB; k++) D[lane * PQ + k] = (k <= lane) ? a[k] : 0.0;
+      }
+      if (badcol && lane == 0) atomicCAS(info, 0, (int)(j0 + jb * 32 + badcol));
+    }
+    __syncthreads();
+    TSTAMP(3 + jb * 4);
+    const int nrows = (3 - jb) * 32;
+    if (tid < nrows) {
+      /* rows below: x L^T = b, one row per thread */
+      double *R = S + pblk(jb + 1 + (tid >> 5), jb) + (tid & 31) * PQ;
+      double x[CB];
+#pragma unroll
+      for (int k = 0; k < CB; k++) x[k] = R[k];
+      /* four partial sums per entry: a dependent v_fma_f64 issues every ~16 cycles */
+#pragma unroll
+      for (int j = 0; j < CB; j++) {
+        double p[4] = {x[j], 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < j; k++) p[k & 3] = fma(-x[k], D[j * PQ + k], p[k & 3]);
+        x[j] = ((p[0] + p[1]) + (p[2] + p[3])) * sInv[jb * 32 + j];
+      }
+#pragma unroll
+      for (int k = 0; k < CB; k++) R[k] = x[k];
+    } else if (tid >= 128 && tid < 160) {
+      /* meanwhile wave 2 inverts the diagonal block: thread c solves L x = e_c */
+      const int c = tid - 128;
+      double x[CB];
+#pragma unroll
+      for (int i = 0; i < CB; i++) {
+        double p[4] = {(i == c) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < i; k++) p[k & 3] = fma(-D[i * PQ + k], x[k], p[k & 3]);
+        x[i] = ((p[0] + p[1]) + (p[2] + p[3])) * sInv[jb * 32 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < CB; i++) Dv[jb * PBLK + i * PQ + c] = x[i];
+    }
+    __syncthreads();
+    TSTAMP(4 + jb * 4);
+    /* trailing update: blk(bi,bj) -= blk(bi,jb) blk(bj,jb)^T for jb < bj <= bi */
+    const int nt = 3 - jb, npairs = nt * (nt + 1) / 2;
+    for (int u = wave; u < npairs * 4; u += 4) {
+      const int pr = u >> 2, f = u & 3;
+      int ri = 0;
+      while ((ri + 1) * (ri + 2) / 2 <= pr) ri++;
+      const int rj = pr - ri * (ri + 1) / 2;
+      const int bi = jb + 1 + ri, bj = jb + 1 + rj;
+      double *Cb = S + pblk(bi, bj);
+      double4_t c = frag_load(Cb, f >> 1, f & 1, lane);
+      c = frag_nt(S + pblk(bi, jb), S + pblk(bj, jb), f >> 1, f & 1, lane, c, -1.0);
+      frag_store(Cb, f >> 1, f & 1, lane, c);
+    }
+    if (nt) __syncthreads();
+  }
+
+  TSTAMP(18);
+  /* L -> A (lower part only); the diagonal 32-blocks also -> diag_store in the format of
+     chol_base_kernel, so that chol_diag_writeback_kernel rewrites the same values */
+  {
+    const int r8 = tid >> 5, k = tid & 31;
+#pragma unroll
+    for (int t = 0; t < 40; t++) {
+      constexpr int BI[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, BJ[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+      const int b = t >> 2, r = (t & 3) * 8 + r8, bi = BI[b], bj = BJ[b];
+      const double v = S[b * PBLK + r * PQ + k];
+      if (bi != bj || k <= r) Ab[(size_t)(bi * 32 + r) * lda + bj * 32 + k] = v;
+      if (bi == bj) diag_store[(j0 / CB + bi) * (CB * CB) + r * CB + k] = (k <= r) ? v : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int b = t >> 2, r = (t & 3) * 8 + r8;
+      Dinvg[b * 1024 + r * 32 + k] = Dv[b * PBLK + r * PQ + k];
+    }
+  }
+  TSTAMP(19);
+}
+
+/* rows below a 128-wide diagonal block: X = B L^-T in place.  64 rows per workgroup, wave w owns rows
+   16w..16w+15 for all four 32-column steps, so the steps need no workgroup barrier. */
+__global__ void __launch_bounds__(256)
+chol_trsm128_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, const double *__restrict__ Dinvg)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *Bt = sm;                     /* [64][TR_LD] */
+  double *Lb = Bt + 64 * TR_LD;        /* 6 off-diagonal blocks of L: (bi, bj) at bi(bi-1)/2 + bj */
+  double *Dvb = Lb + 6 * PBLK;         /* 4 inverted diagonal blocks */
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const size_t row0 = j0 + PB + (size_t)blockIdx.x * 64;
+  {
+    /* one round trip: every global load is issued before the first LDS store */
+    double2 vb[16];
+    double vl[24], vd[16];
+    const int r8 = tid >> 5, k = tid & 31;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int e = t * 256 + tid, r = e >> 6, k2 = (e & 63) * 2;
+      const size_t grow = row0 + r < n ? row0 + r : n - 1;
+      vb[t] = *reinterpret_cast<const double2 *>(A + grow * lda + j0 + k2);
+    }
+#pragma unroll
+    for (int t = 0; t < 24; t++) {
+      constexpr int BI[6] = {1, 2, 2, 3, 3, 3}, BJ[6] = {0, 0, 1, 0, 1, 2};
+      const int b = t >> 2, r = (t & 3) * 8 + r8;
+      vl[t] = A[(j0 + BI[b] * 32 + r) * lda + j0 + BJ[b] * 32 + k];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; t++) vd[t] = Dinvg[(t >> 2) * 1024 + ((t & 3) * 8 + r8) * 32 + k];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int e = t * 256 + tid, r = e >> 6, k2 = (e & 63) * 2;
+      Bt[r * TR_LD + k2] = vb[t].x; Bt[r * TR_LD + k2 + 1] = vb[t].y;
+    }
+#pragma unroll
+    for (int t = 0; t < 24; t++) Lb[(t >> 2) * PBLK + ((t & 3) * 8 + r8) * PQ + k] = vl[t];
+#pragma unroll
+    for (int t = 0; t < 16; t++) Dvb[(t >> 2) * PBLK + ((t & 3) * 8 + r8) * PQ + k] = vd[t];
+  }
+  __syncthreads();
+
+  double *arow = Bt + (wave * 16 + fr) * TR_LD + fq;        /* A-operand view of this wave's rows */
+  double *drow = Bt + (wave * 16 + fq) * TR_LD + fr;        /* accumulator (D layout) view */
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    double4_t acc[2];
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) acc[f][rg] = drow[4 * rg * TR_LD + c * 32 + f * 16];
+#pragma unroll
+    for (int p = 0; p < c; p++) {
+      const double *lb = Lb + (c * (c - 1) / 2 + p) * PBLK + fr * PQ + fq;
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) {
+        const double a = -arow[p * 32 + kk * 4];
+#pragma unroll
+        for (int f = 0; f < 2; f++) acc[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[f * 16 * PQ + kk * 4], acc[f], 0, 0, 0);
+      }
+    }
+    /* Y -> LDS (own rows), then X_c = Y Dinv_c^T (Dinv lower triangular: fragment f needs K = 16(f+1)) */
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) drow[4 * rg * TR_LD + c * 32 + f * 16] = acc[f][rg];
+    const double *db = Dvb + c * PBLK + fr * PQ + fq;
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+      acc[f] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < (f + 1) * 4; kk++)
+        acc[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[c * 32 + kk * 4], db[f * 16 * PQ + kk * 4], acc[f], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        drow[4 * rg * TR_LD + c * 32 + f * 16] = acc[f][rg];
+        const size_t grow = row0 + wave * 16 + fq + 4 * rg;
+        if (grow < n) A[grow * lda + j0 + c * 32 + f * 16 + fr] = acc[f][rg];
+      }
+  }
+}
+
 /* upper(i<j) <- lower(j,i)  (matrix/swap_source.c:213, cholesky.c:103) */
 __global__ void __launch_bounds__(256)
 tricpy_lower_to_upper_kernel(double *__restrict__ A, size_t lda, size_t n)
@@ -177,10 +506,39 @@ static int join_pend(gsl_sinterp_hip_ctx *ctx, Pend *p)
   return ST_SUCCESS;
 }
 
+/* width of the left part of a panel of width w > CB: half, rounded up to a 128-column boundary while
+   the panel is wider than 128 (so the recursion ends in exact 128-wide panels), to 32 below */
+static size_t chol_split(size_t w)
+{
+  const size_t unit = w > PB ? PB : CB;
+  size_t w1 = ((w / 2 + unit - 1) / unit) * unit;
+  if (w1 >= w) w1 = w - unit;
+  return w1;
+}
+
 static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, size_t j0, size_t w, int *d_info,
                       double *d_diag, int depth, Pend *pend)
 {
   int st;
+  static const bool no_p128 = getenv("GSL_SINTERP_NO_PANEL128") && getenv("GSL_SINTERP_NO_PANEL128")[0] == '1';
+  if (w == PB && !no_p128 && (lda & 1) == 0 && ((((uintptr_t)(A + j0 * lda + j0)) & 15) == 0)) {
+    if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
+    double *d_linv = d_diag + ((n + CB - 1) / CB) * (CB * CB);   /* 4 inverted 32x32 blocks */
+    const size_t lds_diag = (size_t)(14 * PBLK + 128) * sizeof(double), lds_trsm = (size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+      HIP_OK(ctx, hipFuncSetAttribute((const void *)chol_diag128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag));
+      HIP_OK(ctx, hipFuncSetAttribute((const void *)chol_trsm128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trsm));
+      attr = true;
+    }
+    hipLaunchKernelGGL(chol_diag128_kernel, dim3(1), dim3(256), lds_diag, ctx->stream, A, lda, j0, d_info, d_diag, d_linv);
+    const size_t below = n - j0 - w;
+    if (below)
+      hipLaunchKernelGGL(chol_trsm128_kernel, dim3((unsigned)((below + 63) / 64)), dim3(256), lds_trsm, ctx->stream, A, lda, n, j0,
+                         (const double *)d_linv);
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
   if (w <= CB) {
     if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
     const size_t below = n - j0 - w;
@@ -189,8 +547,7 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }
-  size_t w1 = ((w / 2 + CB - 1) / CB) * CB;
-  if (w1 >= w) w1 = w - CB;
+  const size_t w1 = chol_split(w);
   st = chol_panel(ctx, A, lda, n, j0, w1, d_info, d_diag, depth + 1, pend);
   if (st) return st;
   if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
@@ -202,8 +559,7 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
     return chol_panel(ctx, A, lda, n, r0, w2, d_info, d_diag, depth + 1, NULL);
   }
   /* same split the recursion on the right half will make */
-  size_t w2a = ((w2 / 2 + CB - 1) / CB) * CB;
-  if (w2a >= w2) w2a = w2 - CB;
+  const size_t w2a = chol_split(w2);
   const size_t w2b = w2 - w2a, rb = r0 + w2a;
   if (!ctx->la_stream[depth]) HIP_OK(ctx, hipStreamCreateWithFlags(&ctx->la_stream[depth], hipStreamNonBlocking));
   hipStream_t aux = ctx->la_stream[depth], mainst = ctx->stream;
@@ -236,7 +592,7 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
   int *d_info = (int *)ctx->d_scratch + 8;
   const size_t nblk = (n + CB - 1) / CB;
   void *d_diag = NULL;
-  int st = sinterp_workspace(ctx, nblk * CB * CB * sizeof(double), &d_diag);
+  int st = sinterp_workspace(ctx, (nblk * CB * CB + PB * PB) * sizeof(double), &d_diag);   /* diagonal blocks + one L^-1 */
   if (st) return st;
   st = sinterp_streamk_prepare(ctx);
   if (st) return st;

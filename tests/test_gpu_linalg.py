@@ -20,7 +20,7 @@ def spd(n, seed):
     return np.tril(m) + np.tril(m, -1).T + 10.0 * n * np.eye(n)      # linalg/test_common.c:68-88
 
 
-@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 64, 100, 257, 1000, 2048, 3000])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 64, 100, 128, 160, 256, 257, 384, 1000, 1152, 2048, 3000])
 def test_cholesky_decomp_and_solve(pkg, orc, n):
     a = spd(n, n)
     b = np.arange(1, n + 1, dtype=np.float64)
@@ -55,6 +55,13 @@ def test_cholesky_rejects_indefinite(pkg):
     d_a = dev(a)
     st, info = ctx.cholesky_decomp1(n, ptr(d_a), n)
     assert st == pkg.capi.GSL_EDOM and info == 151
+    # inside a 128-wide panel (chol_diag128_kernel), second panel, third 32-step
+    n = 512
+    a = spd(n, 2)
+    a[200, 200] = -1.0
+    d_a = dev(a)
+    st, info = ctx.cholesky_decomp1(n, ptr(d_a), n)
+    assert st == pkg.capi.GSL_EDOM and info == 201
 
 
 @pytest.mark.parametrize("n", [2, 3, 4, 12])
