@@ -176,6 +176,14 @@ __device__ __forceinline__ void frag_store(double *Cb, int fi, int fj, int lane,
   for (int rg = 0; rg < 4; rg++) Cb[(fi * 16 + (lane >> 4) + 4 * rg) * PQ + fj * 16 + (lane & 15)] = c[rg];
 }
 
+#ifdef SINTERP_DIAG_PROF
+__device__ unsigned long long g_diag_ts[80];
+#define TSTAMP(i) do { if (threadIdx.x == 0) g_diag_ts[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int gsl_sinterp_hip_debug_diag_ts(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_ts), sizeof(unsigned long long) * 80); }
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
 /* potrf32 on one wave: lane = row, the row's 32 entries in registers, left-looking; compile-time
    recursion over the columns (straight-line code, no branch per column: a failing pivot is recorded
    and reported once at the end).
@@ -198,9 +206,10 @@ __device__ __forceinline__ void potrf32_fill(const double (&a)[CB], const double
 }
 
 template <int J>
-__device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double cur, int &badcol, double &myinv, double *D)
+__device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double cur, int &badcol, const double *D, double *colp, int cstride)
 {
   if constexpr (J < CB) {
+    TSTAMP(32 + J);
     double v = cur;
     if constexpr (J > 0) v = fma(-a[J - 1], lane_bcast(a[J - 1], J), v);
     double d = lane_bcast(v, J);
@@ -238,20 +247,12 @@ __device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double c
     const double sd = fma(fma(-sd0, sd0, d), 0.5 * inv, sd0);
     potrf32_fill<J, 6>(a, r, p);
     a[J] = (lane == J) ? sd : an;
-    myinv = (lane == J) ? inv : myinv;
-    D[lane * PQ + J] = a[J];                            /* column J of L, for the row reads of later columns */
+    colp[J * cstride] = a[J];                           /* column J of L (row reads of later columns) / of L^-1 */
     potrf32_fill<J, 7>(a, r, p);
-    potrf32_cols<J + 1>(a, lane, (p[0] + p[1]) + (p[2] + p[3]), badcol, myinv, D);
+    potrf32_cols<J + 1>(a, lane, (p[0] + p[1]) + (p[2] + p[3]), badcol, D, colp, cstride);
   }
 }
 
-#ifdef SINTERP_DIAG_PROF
-__device__ unsigned long long g_diag_ts[32];
-#define TSTAMP(i) do { if (threadIdx.x == 0) g_diag_ts[i] = __builtin_readcyclecounter(); } while (0)
-extern "C" int gsl_sinterp_hip_debug_diag_ts(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_ts), sizeof(unsigned long long) * 32); }
-#else
-#define TSTAMP(i) do { } while (0)
-#endif
 
 __global__ void __launch_bounds__(256)
 chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restrict__ info, double *__restrict__ diag_store,
@@ -260,7 +261,6 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *S = sm;                       /* 10 packed blocks of the lower triangle */
   double *Dv = S + 10 * PBLK;           /* 4 blocks: inverses of the diagonal blocks */
-  double *sInv = Dv + 4 * PBLK;         /* 128 reciprocal diagonal entries */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double *Ab = A + j0 * lda + j0;
   TSTAMP(0);
@@ -286,16 +286,20 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
     double *D = S + pblk(jb, jb);
     TSTAMP(2 + jb * 4);
     if (wave == 0) {
-      /* potrf32 (see potrf32_cols); lanes 32..63 duplicate lanes 0..31 */
-      const int l = lane & 31;
+      /* potrf32 (see potrf32_cols).  Lanes 0..31 hold the rows of the diagonal block.  Lanes 32..63
+         produce its inverse with the SAME instruction stream: column c of L^-1 obeys
+            x_c[J] = (I[J][c] - sum_{k<J} L[J][k] x_c[k]) / L[J][J],
+         which is the left-looking update of a "row" whose data is row c of the identity. */
+      const bool is_row = lane < CB;
+      const int c = lane - CB;
       double a[CB];
 #pragma unroll
-      for (int k = 0; k < CB; k++) a[k] = (k <= l) ? D[l * PQ + k] : 0.0;
+      for (int k = 0; k < CB; k++) a[k] = is_row ? ((k <= lane) ? D[lane * PQ + k] : 0.0) : ((k == c) ? 1.0 : 0.0);
+      double *colp = is_row ? D + lane * PQ : Dv + jb * PBLK + c;   /* entry J of this lane's vector: colp[J * cstride] */
+      const int cstride = is_row ? 1 : PQ;
       int badcol = 0;
-      double myinv = 1.0;
-      potrf32_cols<0>(a, l, a[0], badcol, myinv, D);
-      if (lane < CB) {
-        sInv[jb * 32 + lane] = myinv;
+      potrf32_cols<0>(a, lane, a[0], badcol, D, colp, cstride);
+      if (is_row) {
 #pragma unroll
         for (int k = 0; k < CB; k++) D[lane * PQ + k] = (k <= lane) ? a[k] : 0.0;
       }
@@ -303,36 +307,22 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
     }
     __syncthreads();
     TSTAMP(3 + jb * 4);
-    const int nrows = (3 - jb) * 32;
-    if (tid < nrows) {
-      /* rows below: x L^T = b, one row per thread */
-      double *R = S + pblk(jb + 1 + (tid >> 5), jb) + (tid & 31) * PQ;
-      double x[CB];
+    /* rows below: X = B Dinv^T on MFMA, one 16-row strip (both column fragments) per unit; Dinv is
+       lower triangular, so the first 16 columns need K = 16 only */
+    for (int u = wave; u < (3 - jb) * 2; u += 4) {
+      double *Bb = S + pblk(jb + 1 + (u >> 1), jb);
+      const int fi = u & 1;
+      const double *ap = Bb + (fi * 16 + (lane & 15)) * PQ + (lane >> 4);
+      const double *bp = Dv + jb * PBLK + (lane & 15) * PQ + (lane >> 4);
+      double4_t x0 = (double4_t){0.0, 0.0, 0.0, 0.0}, x1 = x0;
 #pragma unroll
-      for (int k = 0; k < CB; k++) x[k] = R[k];
-      /* four partial sums per entry: a dependent v_fma_f64 issues every ~16 cycles */
-#pragma unroll
-      for (int j = 0; j < CB; j++) {
-        double p[4] = {x[j], 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < j; k++) p[k & 3] = fma(-x[k], D[j * PQ + k], p[k & 3]);
-        x[j] = ((p[0] + p[1]) + (p[2] + p[3])) * sInv[jb * 32 + j];
+      for (int kk = 0; kk < 8; kk++) {
+        const double av = ap[kk * 4];
+        if (kk < 4) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[kk * 4], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[16 * PQ + kk * 4], x1, 0, 0, 0);
       }
-#pragma unroll
-      for (int k = 0; k < CB; k++) R[k] = x[k];
-    } else if (tid >= 128 && tid < 160) {
-      /* meanwhile wave 2 inverts the diagonal block: thread c solves L x = e_c */
-      const int c = tid - 128;
-      double x[CB];
-#pragma unroll
-      for (int i = 0; i < CB; i++) {
-        double p[4] = {(i == c) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < i; k++) p[k & 3] = fma(-D[i * PQ + k], x[k], p[k & 3]);
-        x[i] = ((p[0] + p[1]) + (p[2] + p[3])) * sInv[jb * 32 + i];
-      }
-#pragma unroll
-      for (int i = 0; i < CB; i++) Dv[jb * PBLK + i * PQ + c] = x[i];
+      frag_store(Bb, fi, 0, lane, x0);
+      frag_store(Bb, fi, 1, lane, x1);
     }
     __syncthreads();
     TSTAMP(4 + jb * 4);
@@ -524,7 +514,7 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
   if (w == PB && !no_p128 && (lda & 1) == 0 && ((((uintptr_t)(A + j0 * lda + j0)) & 15) == 0)) {
     if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
     double *d_linv = d_diag + ((n + CB - 1) / CB) * (CB * CB);   /* 4 inverted 32x32 blocks */
-    const size_t lds_diag = (size_t)(14 * PBLK + 128) * sizeof(double), lds_trsm = (size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double);
+    const size_t lds_diag = (size_t)(14 * PBLK) * sizeof(double), lds_trsm = (size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double);
     static bool attr = false;
     if (!attr) {
       HIP_OK(ctx, hipFuncSetAttribute((const void *)chol_diag128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag));

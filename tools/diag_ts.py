@@ -11,7 +11,7 @@ for _ in range(3):
     d = d0.clone(); st, info = ctx.cholesky_decomp1(n, d.data_ptr(), n)
 torch.cuda.synchronize()
 lib = pkg.capi.lib()
-out = (ctypes.c_ulonglong * 32)()
+out = (ctypes.c_ulonglong * 80)()
 lib.gsl_sinterp_hip_debug_diag_ts(out)
 t = np.array(list(out), dtype=np.int64)
 names = {0:'start',1:'loaded',18:'factored',19:'end'}
@@ -20,3 +20,5 @@ for jb in range(4):
 prev = t[0]
 for i in sorted(names):
     print('%-16s %8d ticks  (+%d)' % (names[i], t[i]-t[0], t[i]-prev)); prev = t[i]
+
+print('per-column ticks of the last potrf32 (jb=3):', [int(t[33+j]-t[32+j]) for j in range(31)])
