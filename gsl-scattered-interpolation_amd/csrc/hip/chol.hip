@@ -880,6 +880,134 @@ trsv_sweep_inv_kernel(const double *__restrict__ T, size_t ldt, size_t n, double
   }
 }
 
+/* ---- the whole sweep in ONE launch ----------------------------------------------------------
+   A sweep is a chain of nblk dependent block steps; as one launch per step it costs ~10 us per
+   step of pure launch/drain latency (C3: 512 steps per solve).  Here workgroup w owns block w of
+   the sweep order (and w + G, ... when there are more blocks than CUs): it streams the tiles
+   T(I, J) of its block row against the already published x_J -- waiting on a per-block flag, the
+   tile itself is fetched before the wait -- then x_I = W_I (b_I - sum), publishes x_I with
+   agent-scope (sc1) stores and raises flag[I].  A workgroup only ever waits on blocks earlier in
+   the sweep order, which belong to workgroups dispatched before it: no deadlock.  b is read only. */
+__global__ void __launch_bounds__(256)
+trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const double *__restrict__ b, double *xout, size_t ldb,
+                     int nrhs, int mode, const double *__restrict__ Dinv, unsigned *flags, unsigned nblk)
+{
+  __shared__ double sx[2][TRSV_MAXR][TS];
+  __shared__ double sW[TS][TS + 1];
+  __shared__ double srhs[TRSV_MAXR][TS];
+  __shared__ double s_part[TRSV_MAXR][4][TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rsub = lane >> 3, c8 = (lane & 7) * 8;
+  for (unsigned t = blockIdx.x; t < nblk; t += gridDim.x) {
+    const unsigned I = (mode == 0) ? t : nblk - 1 - t;
+    const size_t i0 = (size_t)I * TS;
+    const int nbI = (int)((n - i0) < TS ? (n - i0) : TS);
+    __syncthreads();                                     /* previous block of this workgroup fully done with LDS */
+    for (int e = tid; e < TS * TS; e += 256) sW[e / TS][e % TS] = Dinv[(size_t)I * (TS * TS) + e];
+    double acc[TRSV_MAXR][2];
+#pragma unroll
+    for (int r = 0; r < TRSV_MAXR; r++) acc[r][0] = acc[r][1] = 0.0;
+    for (unsigned sstep = 0; sstep < t; sstep++) {
+      const unsigned J = (mode == 0) ? sstep : nblk - 1 - sstep;
+      const size_t j0 = (size_t)J * TS;
+      /* this thread's slice of the tile: independent of x_J, in flight while we wait for the flag */
+      double tt[16];
+      if (mode == 1) {
+        /* T(J rows, I columns), used transposed: lane = column, wave = 16-row group */
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+          const size_t jr = j0 + wave * 16 + jj;
+          tt[jj] = (jr < n && lane < nbI) ? T[jr * ldt + i0 + lane] : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+          const size_t i = i0 + pass * 32 + wave * 8 + rsub;
+          const double *row = T + i * ldt + j0 + c8;
+          if (i < n && j0 + TS <= n && ((((uintptr_t)row) & 15) == 0)) {
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) { const double2 v = *reinterpret_cast<const double2 *>(row + k); tt[pass * 8 + k] = v.x; tt[pass * 8 + k + 1] = v.y; }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) tt[pass * 8 + k] = (i < n && j0 + c8 + k < n) ? row[k] : 0.0;
+          }
+        }
+      }
+      const int buf = sstep & 1;
+      for (int e = tid; e < nrhs * TS; e += 256) {        /* nrhs can be 5: more entries than threads */
+        const int r = e / TS, c = e % TS;
+        while (__hip_atomic_load(flags + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+        sx[buf][r][c] = (j0 + c < n) ? __hip_atomic_load(xout + r * ldb + j0 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+      __syncthreads();
+      if (mode == 1) {
+#pragma unroll
+        for (int r = 0; r < TRSV_MAXR; r++)
+          if (r < nrhs) {
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) acc[r][0] = fma(tt[jj], sx[buf][r][wave * 16 + jj], acc[r][0]);
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < TRSV_MAXR; r++)
+          if (r < nrhs) {
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+              for (int k = 0; k < 8; k++) acc[r][pass] = fma(tt[pass * 8 + k], sx[buf][r][c8 + k], acc[r][pass]);
+          }
+      }
+    }
+    /* reduce the partial sums: b_I - sum -> srhs */
+    if (mode == 1) {
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++) if (r < nrhs) s_part[r][wave][lane] = acc[r][0];
+      __syncthreads();
+      for (int e = tid; e < nrhs * TS; e += 256) {
+        const int r = e / TS, c = e % TS;
+        const double sum = (s_part[r][0][c] + s_part[r][1][c]) + (s_part[r][2][c] + s_part[r][3][c]);
+        srhs[r][c] = (c < nbI) ? b[r * ldb + i0 + c] - sum : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++)
+        if (r < nrhs) {
+#pragma unroll
+          for (int pass = 0; pass < 2; pass++) {
+            double a = acc[r][pass];
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            const int row = pass * 32 + wave * 8 + rsub;
+            if ((lane & 7) == 0) srhs[r][row] = (row < nbI) ? b[r * ldb + i0 + row] - a : 0.0;
+          }
+        }
+    }
+    __syncthreads();
+    /* x_I = W srhs  (W = Dinv for the forward sweep, Dinv^T for the backward ones) */
+    for (int r = wave; r < nrhs; r += 4) {
+      double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+      if (mode == 0) {
+#pragma unroll
+        for (int c = 0; c < TS; c += 4) {
+          p0 = fma(sW[lane][c], srhs[r][c], p0); p1 = fma(sW[lane][c + 1], srhs[r][c + 1], p1);
+          p2 = fma(sW[lane][c + 2], srhs[r][c + 2], p2); p3 = fma(sW[lane][c + 3], srhs[r][c + 3], p3);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < TS; c += 4) {
+          p0 = fma(sW[c][lane], srhs[r][c], p0); p1 = fma(sW[c + 1][lane], srhs[r][c + 1], p1);
+          p2 = fma(sW[c + 2][lane], srhs[r][c + 2], p2); p3 = fma(sW[c + 3][lane], srhs[r][c + 3], p3);
+        }
+      }
+      if (lane < nbI) __hip_atomic_store(xout + r * ldb + i0 + lane, (p0 + p1) + (p2 + p3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + I, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout,
                          size_t ldb, int nrhs, int mode, int unit, double *d_inv)
 {
@@ -890,6 +1018,16 @@ static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
   if (use_inv) {
     hipLaunchKernelGGL(tri_inv_kernel, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, T, ldt, n, mode == 2 ? 1 : 0, unit, d_inv);
     LAUNCH_CHECK(ctx);
+  }
+  static const bool no_df = getenv("GSL_SINTERP_NO_DATAFLOW_TRSV") && getenv("GSL_SINTERP_NO_DATAFLOW_TRSV")[0] == '1';
+  if (use_inv && !no_df && ctx->sk_wgs > 0) {
+    unsigned *d_flags = (unsigned *)(d_inv + nblk * TS * TS);
+    HIP_OK(ctx, hipMemsetAsync(d_flags, 0, nblk * sizeof(unsigned), ctx->stream));
+    const unsigned G = (unsigned)(nblk < (size_t)ctx->sk_wgs ? nblk : (size_t)ctx->sk_wgs);
+    hipLaunchKernelGGL(trsv_dataflow_kernel, dim3(G), dim3(256), 0, ctx->stream, T, ldt, n, (const double *)b, xout, ldb, nrhs, mode,
+                       (const double *)d_inv, d_flags, (unsigned)nblk);
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
   }
   for (size_t t = 0; t < nblk; t++) {
     const size_t blk = (mode == 0) ? t : nblk - 1 - t;
@@ -921,7 +1059,9 @@ int sinterp_trsv_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size
   int st = sinterp_graph_try_launch(ctx, slot, n, key_lda, T, p1, &replayed);
   if (st || replayed) return st;
   void *d_inv = NULL;
-  st = sinterp_invbuf(ctx, ((n + TS - 1) / TS) * TS * TS * sizeof(double), &d_inv);
+  st = sinterp_invbuf(ctx, ((n + TS - 1) / TS) * (TS * TS * sizeof(double) + sizeof(unsigned)), &d_inv);   /* inverses + flags */
+  if (st) return st;
+  st = sinterp_streamk_prepare(ctx);                   /* CU count (the dataflow sweep needs co-resident workgroups) */
   if (st) return st;
   hipStream_t saved;
   st = sinterp_capture_begin(ctx, &saved);

@@ -172,3 +172,21 @@ def test_gemm_stream_k_is_reproducible(pkg):
     want = Cm - A @ A.T
     rows, cols = np.indices((m, n))
     assert np.abs(outs[0] - want)[cols <= rows].max() <= 1e-12 * k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [16640, 4100])
+def test_single_launch_sweeps_more_blocks_than_cus(pkg, n):
+    """The dataflow sweep kernel gives one 64-row block to each workgroup; with n = 16640 there are
+    260 blocks for 256 CUs, so some workgroups own two.  Property check at full size (no oracle run):
+    (L L^T) x = b with a synthetic well-conditioned factor, residual computed with torch on the GPU."""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    L = torch.rand((n, n), dtype=torch.float64, device="cuda", generator=g)
+    L = torch.tril(L, -1) / n + torch.diag(1.0 + torch.rand(n, dtype=torch.float64, device="cuda", generator=g))
+    xs = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    b = L @ (L.T @ xs)
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_x = b.clone()
+    ctx.cholesky_svx(n, ptr(L), n, ptr(d_x))            # raises on a non-zero status
+    ctx.sync()
+    assert float((d_x - xs).abs().max()) <= 1e-11 * float(xs.abs().max())
