@@ -349,13 +349,13 @@ struct StreamK {
   unsigned *flags;              /* [G] */
 };
 
-template <int BM>
+template <int BM, int BN>
 __device__ __forceinline__ void decode_tile(const GemmArgs &g, unsigned tile, int &tm, int &tn)
 {
   if (!g.lower_only) {
     tm = (int)(tile / g.tiles_n); tn = (int)(tile % g.tiles_n);
   } else {
-    constexpr unsigned R = BM / GT_BN;
+    constexpr unsigned R = BM / BN;
     const unsigned full_rows = (unsigned)g.tiles_n / R;
     const unsigned tri = R * full_rows * (full_rows + 1) / 2;
     if (tile < tri) {
@@ -371,15 +371,23 @@ __device__ __forceinline__ void decode_tile(const GemmArgs &g, unsigned tile, in
   }
 }
 
-template <int WR>
-__global__ void __launch_bounds__(128 * WR, 1)
+/* Tile configurations (block tile BM x BN, wave tile WM x WN):
+     256x128 / 64x64, 8 waves, 144 KiB LDS -- large updates, 2 waves per SIMD;
+     128x128 / 64x64, 4 waves,  96 KiB
+      64x64  / 32x32, 4 waves,  48 KiB     -- updates with few 128-tiles (the K <= 512 levels of the
+                                             recursions): 4x the workgroups, a 128-wide panel update
+                                             is otherwise one 13.7 us tile per CU on a fraction of the CUs */
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 1)
 gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 {
-  constexpr int BM = 64 * WR;
-  constexpr int NW = 2 * WR;
-  constexpr int NT = 128 * WR;                          /* threads */
-  constexpr int A_TILE = BM * GT_BK, B_TILE = GT_BN * GT_BK;
-  constexpr int A_CH = BM / 8 / NW, B_CH = (GT_BN / 8) / NW;
+  constexpr int WCOLS = BN / WN;                        /* waves along n */
+  constexpr int NW = (BM / WM) * WCOLS;
+  constexpr int NT = NW * 64;                           /* threads */
+  constexpr int FM = WM / 16, FN = WN / 16;             /* MFMA fragments per wave */
+  constexpr int A_TILE = BM * GT_BK, B_TILE = BN * GT_BK;
+  constexpr int A_CH = BM / 8 / NW, B_CH = (BN / 8) / NW;
+  static_assert(A_CH >= 1 && B_CH >= 1 && A_CH * 8 * NW == BM && B_CH * 8 * NW == BN, "tile / wave split");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *sA = smem;
   double *sB = smem + DM_STAGES * A_TILE;
@@ -397,10 +405,10 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
     const unsigned s0 = it - tile_first;
     const unsigned s1 = it_end < tile_end ? it_end - tile_first : x.steps;
     int tm, tn;
-    decode_tile<BM>(g, tile, tm, tn);
-    const size_t row0 = (size_t)tm * BM, col0 = (size_t)tn * GT_BN;
+    decode_tile<BM, BN>(g, tile, tm, tn);
+    const size_t row0 = (size_t)tm * BM, col0 = (size_t)tn * BN;
 
-    double4_t acc[4][4];
+    double4_t acc[FM][FN];
     {
       /* Everything lane-dependent is derived from a laundered thread id INSIDE the segment: left to
          itself the compiler hoists it all out of the while loop, runs out of VGPRs (the 8-wave
@@ -409,13 +417,13 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
       int tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
       const int lane = tid & 63, wave = tid >> 6;
-      const int wr = wave >> 1, wc = wave & 1;
+      const int wr = wave / WCOLS, wc = wave % WCOLS;
       const int fr = lane & 15, fq = lane >> 4;
       const int sw = (fr >> 1) & 7;
       int koff[4];
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) koff[kk] = (((kk * 2 + (fq >> 1)) ^ sw) << 1) + (fq & 1);
-      const int arow = (wr * 64 + fr) * GT_BK, brow = (wc * 64 + fr) * GT_BK;
+      const int arow = (wr * WM + fr) * GT_BK, brow = (wc * WN + fr) * GT_BK;
 
       const double *srcA[A_CH], *srcB[B_CH];
 #pragma unroll
@@ -436,9 +444,9 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
       };
 
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < FM; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < FN; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
       __syncthreads();                                   /* the ring is free: previous segment fully read */
       issue(0, (size_t)s0 * GT_BK);
@@ -446,8 +454,9 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
       for (unsigned s = s0; s < s1; s++) {
         const unsigned rel = s - s0;
         if (s + 1 < s1) {
-          if (A_CH + B_CH == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          if constexpr (A_CH + B_CH == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else if constexpr (A_CH + B_CH == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else { static_assert(A_CH + B_CH == 4 || A_CH + B_CH == 6 || A_CH + B_CH == 8, "vmcnt immediate"); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -456,15 +465,15 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
         const double *b_base = sB + (rel % DM_STAGES) * B_TILE + brow;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-          double af[4], bf[4];
+          double af[FM], bf[FN];
 #pragma unroll
-          for (int i = 0; i < 4; i++) af[i] = a_base[i * 16 * GT_BK + koff[kk]];
+          for (int i = 0; i < FM; i++) af[i] = a_base[i * 16 * GT_BK + koff[kk]];
 #pragma unroll
-          for (int j = 0; j < 4; j++) bf[j] = b_base[j * 16 * GT_BK + koff[kk]];
+          for (int j = 0; j < FN; j++) bf[j] = b_base[j * 16 * GT_BK + koff[kk]];
 #pragma unroll
-          for (int i = 0; i < 4; i++)
+          for (int i = 0; i < FM; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < FN; j++)
               acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
       }
@@ -475,18 +484,18 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
     size_t row0e = row0, col0e = col0;
     asm volatile("" : "+v"(tid), "+s"(row0e), "+s"(col0e));
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int fr = lane & 15, fq = lane >> 4;
     if (s0 != 0) {
       /* not the owner: publish the partial tile */
-      double *pp = x.partial + (size_t)gl * (BM * GT_BN) + tid;
+      double *pp = x.partial + (size_t)gl * (BM * BN) + tid;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < FM; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < FN; j++)
 #pragma unroll
           for (int rg = 0; rg < 4; rg++)
-            __hip_atomic_store(pp + ((i * 4 + j) * 4 + rg) * NT, acc[i][j][rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + ((i * FN + j) * 4 + rg) * NT, acc[i][j][rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,27 +508,27 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
           if (tid == 0)
             while (__hip_atomic_load(x.flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
           __syncthreads();
-          const double *pp = x.partial + (size_t)w * (BM * GT_BN) + tid;
+          const double *pp = x.partial + (size_t)w * (BM * BN) + tid;
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
+          for (int i = 0; i < FM; i++) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < FN; j++)
 #pragma unroll
               for (int rg = 0; rg < 4; rg++)
-                acc[i][j][rg] += __hip_atomic_load(pp + ((i * 4 + j) * 4 + rg) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc[i][j][rg] += __hip_atomic_load(pp + ((i * FN + j) * 4 + rg) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_sched_barrier(0);            /* 16 loads in flight at a time */
           }
           if (tid == 0) __hip_atomic_store(x.flags + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < FM; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const size_t gcol = col0e + wc * 64 + j * 16 + fr;
+        for (int j = 0; j < FN; j++) {
+          const size_t gcol = col0e + wc * WN + j * 16 + fr;
 #pragma unroll
           for (int rg = 0; rg < 4; rg++) {
-            const size_t grow = row0e + wr * 64 + i * 16 + fq + 4 * rg;
+            const size_t grow = row0e + wr * WM + i * 16 + fq + 4 * rg;
             if (!g.lower_only || gcol <= grow) {
               double *p = g.C + grow * g.ldc + gcol;
               *p = *p - acc[i][j][rg];
@@ -664,16 +673,27 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       x.partial = ctx->d_sk_partial; x.flags = ctx->d_sk_flags;
       GemmArgs h = g;
       unsigned tiles = grid;
-      bool w8 = !no_w8 && (m % 256 == 0) && (!lower_only || (g.tiles_n % 2) == 0);
-      if (w8) {
-        h.tiles_m = (int)(m / 256);
-        tiles = (unsigned)h.tiles_m * (unsigned)h.tiles_n;
+      int cfg = 1;                                       /* 0: 256x128, 1: 128x128, 2: 64x64 */
+      if (!no_w8 && (m % 256 == 0) && (!lower_only || (g.tiles_n % 2) == 0)) {
+        GemmArgs h8 = g;
+        h8.tiles_m = (int)(m / 256);
+        unsigned t8 = (unsigned)h8.tiles_m * (unsigned)h8.tiles_n;
         if (lower_only) {
-          const unsigned fr_ = (unsigned)h.tiles_n / 2;
-          tiles = 2 * fr_ * (fr_ + 1) / 2 + ((unsigned)h.tiles_m - fr_) * (unsigned)h.tiles_n;
+          const unsigned fr_ = (unsigned)h8.tiles_n / 2;
+          t8 = 2 * fr_ * (fr_ + 1) / 2 + ((unsigned)h8.tiles_m - fr_) * (unsigned)h8.tiles_n;
         }
         /* the big tile only pays when every CU gets a few K-steps of it */
-        if ((unsigned long long)tiles * x.steps < 16ull * (unsigned)ctx->sk_wgs) { w8 = false; h = g; tiles = grid; }
+        if ((unsigned long long)t8 * x.steps >= 16ull * (unsigned)ctx->sk_wgs) { cfg = 0; h = h8; tiles = t8; }
+      }
+      static const bool no_t64 = getenv("GSL_SINTERP_NO_GEMM64") && getenv("GSL_SINTERP_NO_GEMM64")[0] == '1';
+      if (cfg == 1 && !no_t64 && 2u * grid <= (unsigned)ctx->sk_wgs) {
+        /* 128-tiles for at most half of the CUs: quarter tiles, 4x the workgroups (measured: with
+           more tiles than that the extra prologues/epilogues cost more than the idle CUs) */
+        cfg = 2;
+        h.tiles_m = (int)(m / 64); h.tiles_n = (int)(n / 64);
+        if (lower_only && h.tiles_m < h.tiles_n) h.tiles_n = h.tiles_m;
+        tiles = (unsigned)h.tiles_m * (unsigned)h.tiles_n;
+        if (lower_only) { const unsigned tn_ = (unsigned)h.tiles_n; tiles = tn_ * (tn_ + 1) / 2 + ((unsigned)h.tiles_m - tn_) * tn_; }
       }
       const unsigned long long total64 = (unsigned long long)tiles * x.steps;
       unsigned long long want = total64 / 16;            /* >= 16 K-steps per workgroup ... */
@@ -682,15 +702,19 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       const unsigned G = (unsigned)(want ? want : 1);
       if (total64 < 0x7fffffffull) {
       x.total = (unsigned)total64; x.base = x.total / G; x.rem = x.total % G;
-      static bool attr_sk2 = false, attr_sk4 = false;
-      if (w8) {
-        const size_t lds8 = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);
-        if (!attr_sk4) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8)); attr_sk4 = true; }
-        hipLaunchKernelGGL(gemm_minus_streamk_kernel<4>, dim3(G), dim3(512), lds8, ctx->stream, h, x);
+      static bool attr_sk[3] = {false, false, false};
+      if (cfg == 0) {
+        const size_t lds = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);
+        if (!attr_sk[0]) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<256, 128, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_sk[0] = true; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<256, 128, 64, 64>), dim3(G), dim3(512), lds, ctx->stream, h, x);
+      } else if (cfg == 1) {
+        const size_t lds = (size_t)DM_STAGES * (128 + 128) * GT_BK * sizeof(double);
+        if (!attr_sk[1]) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<128, 128, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_sk[1] = true; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<128, 128, 64, 64>), dim3(G), dim3(256), lds, ctx->stream, h, x);
       } else {
-        const size_t lds4 = (size_t)DM_STAGES * (128 + 128) * GT_BK * sizeof(double);
-        if (!attr_sk2) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4)); attr_sk2 = true; }
-        hipLaunchKernelGGL(gemm_minus_streamk_kernel<2>, dim3(G), dim3(256), lds4, ctx->stream, h, x);
+        const size_t lds = (size_t)DM_STAGES * (64 + 64) * GT_BK * sizeof(double);
+        if (!attr_sk[2]) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<64, 64, 32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_sk[2] = true; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<64, 64, 32, 32>), dim3(G), dim3(256), lds, ctx->stream, h, x);
       }
       LAUNCH_CHECK(ctx);
       return ST_SUCCESS;

@@ -131,6 +131,8 @@ def test_lu_singular_reports_edom(pkg):
     (300, 200, 50, 0, 0), (300, 200, 50, 1, 0), (515, 515, 33, 0, 1),   # guarded register-staged kernel
     (1024, 1024, 512, 0, 1), (2304, 384, 1024, 0, 0),    # stream-K, 4-wave: tiles cut in 2 / 4 K-ranges
     (2048, 2048, 2048, 0, 1), (2048, 1024, 1536, 0, 0),  # stream-K, 8-wave: several contributors per tile
+    (4224, 2048, 256, 0, 0), (4224, 2048, 192, 0, 1),    # stream-K, 128x128 tiles (>= 512 tiles, rows not a multiple of 256)
+    (3072, 256, 256, 0, 1), (1920, 128, 128, 0, 1),      # stream-K, 64x64 tiles: panel updates of the recursion's low levels
 ])
 def test_gemm_building_block(pkg, m, n, k, kn, lower):
     """C -= A op(B) on fp64 MFMA vs numpy, for every kernel variant behind gsl_sinterp_hip_gemm_minus."""
