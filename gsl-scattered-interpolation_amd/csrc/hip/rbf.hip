@@ -21,12 +21,13 @@
 
 /* tables live in global memory (built once per context on first use) and are
    copied into LDS by each workgroup */
-#define LOG_BITS 10
+#define LOG_BITS 7
 #define LOG_N (1 << LOG_BITS)
+#define LOG_COPIES 16                 /* LDS replicas of the (1/c, ln c) table: one per lane of a ds_read_b128 pass */
+#define LOG_LDS (LOG_N * LOG_COPIES * 2)   /* doubles: 32 KiB */
 struct RbfTables {
   double exp2_frac[TBL_N];      /* 2^(i/256)                          */
-  double log_inv[LOG_N];        /* 1/c_i, c_i = 1 + (i+0.5)/1024      */
-  double log_val[LOG_N];        /* ln c_i                             */
+  double log_pair[LOG_N][2];    /* {1/c_i, ln c_i}, c_i = (1 + (i+0.5)/128)/2 */
 };
 
 __device__ RbfTables g_rbf_tables;
@@ -38,9 +39,9 @@ static int ensure_tables(gsl_sinterp_hip_ctx *ctx)
   static RbfTables h;
   for (int i = 0; i < TBL_N; i++) h.exp2_frac[i] = exp2((double)i / TBL_N);
   for (int i = 0; i < LOG_N; i++) {
-    double c = 1.0 + ((double)i + 0.5) / LOG_N;
-    h.log_inv[i] = 1.0 / c;
-    h.log_val[i] = log(c);
+    double c = 0.5 * (1.0 + ((double)i + 0.5) / LOG_N);   /* bin midpoint of the frexp mantissa in [1/2, 1) */
+    h.log_pair[i][0] = 1.0 / c;
+    h.log_pair[i][1] = log(c);
   }
   HIP_OK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_rbf_tables), &h, sizeof h, 0, hipMemcpyHostToDevice));
   if (ctx->device < 64) g_tables_ready[ctx->device] = true;
@@ -65,41 +66,51 @@ __device__ __forceinline__ double exp2_tbl(double t, const double *__restrict__ 
   return ldexp(tbl[k & (TBL_N - 1)] * p, k >> TBL_BITS);
 }
 
-/* ln(v), v > 0 finite normal: v = 2^e m, m in [1,2), split with integer ops on the high word;
-   table index = top 10 mantissa bits, u = m/c - 1, |u| <= 2^-11, log1p(u) to u^4 (|u|^5/5 < 6e-18) */
-__device__ __forceinline__ double log_tbl(double v, const double *__restrict__ inv, const double *__restrict__ val)
+/* ln(v), v >= 0 finite: v = 2^e m with m in [1/2, 1) from v_frexp_mant_f64 / v_frexp_exp_i32_f64
+   (one instruction each; splitting the high word with integer ops costs five more).  Table index =
+   top 7 mantissa bits; c_i = (1 + (i+0.5)/128)/2 is the midpoint of m's bin, u = m/c_i - 1,
+   |u| <= 2^-8, log1p(u) to u^6 (|u|^7/7 < 2e-18);  ln v = e ln2 + ln c_i + log1p(u).
+   The lookup is data dependent per lane; a plain LDS table costs ~3x in bank conflicts (measured:
+   31 % of the TPS sweep).  The table is therefore stored as 16 interleaved copies of the 16-byte
+   pair {1/c_i, ln c_i}: row i is 256 bytes = all 64 banks, lane l reads copy l & 15, so each
+   16-lane pass of the ds_read_b128 touches every bank exactly once whatever the indices are.
+   v = 0 gives a finite value (m = 0 -> u = -1), which the callers multiply by r^2 = 0. */
+template <int COPIES>
+__device__ __forceinline__ double log_tbl(double v, const double *__restrict__ lt_lane)
 {
-  const int hi = __double2hiint(v), lo = __double2loint(v);
-  const int e = (hi >> 20) - 1023;
-  const int idx = (hi >> (20 - LOG_BITS)) & (LOG_N - 1);
-  const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
-  const double u = fma(m, inv[idx], -1.0);
-  double p = fma(u, -0.25, 1.0 / 3.0);
+  const int idx = (__double2hiint(v) >> (20 - LOG_BITS)) & (LOG_N - 1);
+  const double2 t = *reinterpret_cast<const double2 *>(lt_lane + idx * (COPIES * 2));
+  const double m = __builtin_amdgcn_frexp_mant(v);
+  const int e = __builtin_amdgcn_frexp_exp(v);
+  const double u = fma(m, t.x, -1.0);
+  double p = fma(u, -1.0 / 6.0, 0.2);
+  p = fma(p, u, -0.25);
+  p = fma(p, u, 1.0 / 3.0);
   p = fma(p, u, -0.5);
   p = fma(p, u, 1.0);
-  return fma((double)e, 0.693147180559945309417232, fma(p, u, val[idx]));
+  return fma((double)e, 0.693147180559945309417232, fma(p, u, t.y));
 }
 
-template <int KIND>
+template <int KIND, int COPIES>
 __device__ __forceinline__ double phi_r2(double r2, double coef, const double *__restrict__ t0,
-                                         const double *__restrict__ t1, const double *__restrict__ t2)
+                                         const double *__restrict__ lt_lane)
 {
   if (KIND == GSL_SINTERP_RBF_GAUSSIAN) {
     return exp2_tbl(r2 * coef, t0);                /* coef = -eps^2 log2(e) */
   } else {
     /* r^2 ln r = 0.5 r^2 ln r^2; the 0.5 is folded into the caller's weight (coef = 0.5 in fill).
-       r2 = 0 (target on a centre): clamped to 1e-300, phi = -7e-298, i.e. 0 to any tolerance */
-    const double rc = fmax(r2, 1e-300);
-    return (coef * rc) * log_tbl(rc, t1, t2);
+       r2 = 0 (target on a centre): log_tbl returns a finite value, the product is exactly 0 */
+    return (coef * r2) * log_tbl<COPIES>(r2, lt_lane);
   }
 }
 
-__device__ __forceinline__ void load_tables(double *s_t0, double *s_t1, double *s_t2, int kind)
+template <int COPIES>
+__device__ __forceinline__ void load_tables(double *s_t0, double *s_lt, int kind)
 {
   if (kind == GSL_SINTERP_RBF_GAUSSIAN) {
     for (int i = threadIdx.x; i < TBL_N; i += blockDim.x) s_t0[i] = g_rbf_tables.exp2_frac[i];
   } else {
-    for (int i = threadIdx.x; i < LOG_N; i += blockDim.x) { s_t1[i] = g_rbf_tables.log_inv[i]; s_t2[i] = g_rbf_tables.log_val[i]; }
+    for (int i = threadIdx.x; i < LOG_N * COPIES * 2; i += blockDim.x) s_lt[i] = g_rbf_tables.log_pair[i / (COPIES * 2)][i & 1];
   }
 }
 
@@ -109,8 +120,10 @@ template <int KIND, int DIM>
 __global__ void __launch_bounds__(256)
 rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, double *__restrict__ phi, size_t lda)
 {
-  __shared__ double s_t0[TBL_N], s_t1[KIND == GSL_SINTERP_RBF_TPS ? LOG_N : 1], s_t2[KIND == GSL_SINTERP_RBF_TPS ? LOG_N : 1];
-  load_tables(s_t0, s_t1, s_t2, KIND);
+  __shared__ double s_t0[KIND == GSL_SINTERP_RBF_GAUSSIAN ? TBL_N : 1];
+  __shared__ __attribute__((aligned(16))) double s_lt[KIND == GSL_SINTERP_RBF_TPS ? LOG_N * 2 : 2];   /* one copy: the fill is HBM-write bound */
+  load_tables<1>(s_t0, s_lt, KIND);
+  const double *lt_lane = s_lt;
   __syncthreads();
   const size_t j0 = ((size_t)blockIdx.x * 64 + (threadIdx.x & 63)) * 2;
   const size_t ibase = (size_t)blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
@@ -130,8 +143,8 @@ rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
       const double da = xi - xa[c], db = xi - xb[c];
       ra = fma(da, da, ra); rb = fma(db, db, rb);
     }
-    double va = phi_r2<KIND>(ra, coef, s_t0, s_t1, s_t2);
-    double vb = phi_r2<KIND>(rb, coef, s_t0, s_t1, s_t2);
+    double va = phi_r2<KIND, 1>(ra, coef, s_t0, lt_lane);
+    double vb = phi_r2<KIND, 1>(rb, coef, s_t0, lt_lane);
     if (KIND == GSL_SINTERP_RBF_TPS) { va = ra > 0.0 ? va : 0.0; vb = rb > 0.0 ? vb : 0.0; }   /* phi(0) = 0 exactly in the matrix */
     double *dst = phi + i * lda + j0;
     if (two && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<double2 *>(dst) = make_double2(va, vb);
@@ -149,9 +162,11 @@ __global__ void __launch_bounds__(EV_THREADS)
 rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, const double *__restrict__ w,
                 const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm)
 {
-  __shared__ double s_t0[TBL_N], s_t1[KIND == GSL_SINTERP_RBF_TPS ? LOG_N : 1], s_t2[KIND == GSL_SINTERP_RBF_TPS ? LOG_N : 1];
+  __shared__ double s_t0[KIND == GSL_SINTERP_RBF_GAUSSIAN ? TBL_N : 1];
+  __shared__ __attribute__((aligned(16))) double s_lt[KIND == GSL_SINTERP_RBF_TPS ? LOG_LDS : 2];
   __shared__ double s_c[EV_TJ * (DIM + 1)];       /* per centre: x[0..DIM-1], w */
-  load_tables(s_t0, s_t1, s_t2, KIND);
+  load_tables<LOG_COPIES>(s_t0, s_lt, KIND);
+  const double *lt_lane = s_lt + (threadIdx.x & (LOG_COPIES - 1)) * 2;
 
   /* slot i of the (optionally cell-sorted) order -> target index; a lane's TPT targets are
      ADJACENT slots so they are spatial neighbours too */
@@ -201,7 +216,7 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
       }
 #pragma unroll
       for (int t = 0; t < TPT; t++)
-        acc[t] = fma(wj, phi_r2<KIND>(r2[t], KIND == GSL_SINTERP_RBF_TPS ? 1.0 : coef, s_t0, s_t1, s_t2), acc[t]);
+        acc[t] = fma(wj, phi_r2<KIND, LOG_COPIES>(r2[t], KIND == GSL_SINTERP_RBF_TPS ? 1.0 : coef, s_t0, lt_lane), acc[t]);
     }
   }
 #pragma unroll
