@@ -28,6 +28,10 @@ struct gsl_sinterp_hip_ctx {
   size_t inv_bytes;
   void *d_sort;             /* target permutation + cell counters (sort.hip) */
   size_t sort_bytes;
+  void *d_sort2;            /* the same for the centres of the Gaussian sweep */
+  size_t sort2_bytes;
+  void *d_cent;             /* cell-ordered packed centres {x, w} + tile boxes of the Gaussian sweep */
+  size_t cent_bytes;
   /* hipGraph cache: the recursive factorisation drivers issue ~1-2k small, fully static
      launches; they are captured once per (routine, n, lda, pointers) and replayed */
   hipStream_t cap_stream;
@@ -108,5 +112,11 @@ int sinterp_sortbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 /* sort.hip: permutation that groups the targets by cell of a uniform grid (~per_cell each) */
 int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
                          int **d_perm_out);
+/* the centres: cells visited in Morton order (consecutive runs are spatially compact), original
+   index order inside a cell (deterministic summation order); uses its own buffer */
+int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, size_t xtda, int dim, int per_cell,
+                         int **d_perm_out);
+int sinterp_sortbuf2(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
+int sinterp_centbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 
 #endif

@@ -225,6 +225,177 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
 }
 
 /* ------------------------------------------------------------------------ */
+/* Gaussian sweep with tile culling.  At the shape parameters this path is used with
+   (eps ~ 2 N^(1/d)) a target only sees centres within r = sqrt(72 ln 2)/eps of itself -- a few per
+   cent of the cloud -- yet the plain sweep still computes every distance.  Here the centres are
+   put in Morton cell order (sort.hip), packed as {x, w} and cut into tiles of CT consecutive
+   (hence spatially compact) centres with a bounding box each; a workgroup -- whose 512 targets are
+   neighbours too, thanks to the target sort -- first collects the tiles whose box comes within
+   the cut-off of ITS targets' box (one ballot per 64 tiles, kept as bit masks: ascending order,
+   no atomics) and then runs the usual inner loop over those tiles only.  The criterion is the
+   one of the per-centre early-out (term < 2^-72 of the kernel maximum), applied to a lower bound
+   of the distance, so only terms below that bound are dropped; the summation order is the (fixed)
+   Morton order of the centres instead of their input order. */
+#define CT 128
+#define CULL_MAX_TILES 4096
+
+template <int DIM>
+__global__ void __launch_bounds__(CT)
+centre_pack_kernel(const double *__restrict__ x, size_t n, size_t xtda, const double *__restrict__ w,
+                   const int *__restrict__ perm, double *__restrict__ xs, double *__restrict__ tbox)
+{
+  __shared__ double s_lo[DIM][2], s_hi[DIM][2];
+  const size_t i = (size_t)blockIdx.x * CT + threadIdx.x;
+  const bool ok = i < n;
+  double v[DIM];
+  if (ok) {
+    const size_t j = (size_t)perm[i];
+#pragma unroll
+    for (int c = 0; c < DIM; c++) { v[c] = x[j * xtda + c]; xs[i * (DIM + 1) + c] = v[c]; }
+    xs[i * (DIM + 1) + DIM] = w[j];
+  }
+#pragma unroll
+  for (int c = 0; c < DIM; c++) {
+    double lo = ok ? v[c] : INFINITY, hi = ok ? v[c] : -INFINITY;
+    for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off)); hi = fmax(hi, __shfl_xor(hi, off)); }
+    if ((threadIdx.x & 63) == 0) { s_lo[c][threadIdx.x >> 6] = lo; s_hi[c][threadIdx.x >> 6] = hi; }
+  }
+  __syncthreads();
+  if (threadIdx.x < DIM) {
+    const int c = threadIdx.x;
+    tbox[(size_t)blockIdx.x * (2 * DIM) + 2 * c] = fmin(s_lo[c][0], s_lo[c][1]);
+    tbox[(size_t)blockIdx.x * (2 * DIM) + 2 * c + 1] = fmax(s_hi[c][0], s_hi[c][1]);
+  }
+}
+
+template <int DIM, int TPT>
+__global__ void __launch_bounds__(EV_THREADS)
+rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n, const double *__restrict__ tbox, unsigned ntiles,
+                           const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm)
+{
+  __shared__ double s_t0[TBL_N];
+  __shared__ __attribute__((aligned(16))) double s_c[CT * (DIM + 1)];
+  __shared__ double s_blo[DIM][4], s_bhi[DIM][4];
+  __shared__ unsigned long long s_mask[CULL_MAX_TILES / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < TBL_N; i += EV_THREADS) s_t0[i] = g_rbf_tables.exp2_frac[i];
+
+  const size_t k0 = (((size_t)blockIdx.x * EV_THREADS) + tid) * TPT;
+  size_t kidx[TPT];
+  double yy[TPT][DIM], acc[TPT];
+#pragma unroll
+  for (int t = 0; t < TPT; t++) {
+    const size_t slot = k0 + (size_t)t;
+    kidx[t] = slot < m ? (perm ? (size_t)perm[slot] : slot) : m;
+    acc[t] = 0.0;
+#pragma unroll
+    for (int c = 0; c < DIM; c++) yy[t][c] = kidx[t] < m ? y[kidx[t] * ytda + c] : 0.0;
+  }
+  /* bounding box of this workgroup's targets */
+#pragma unroll
+  for (int c = 0; c < DIM; c++) {
+    double lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < TPT; t++) if (kidx[t] < m) { lo = fmin(lo, yy[t][c]); hi = fmax(hi, yy[t][c]); }
+    for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off)); hi = fmax(hi, __shfl_xor(hi, off)); }
+    if (lane == 0) { s_blo[c][wave] = lo; s_bhi[c][wave] = hi; }
+  }
+  __syncthreads();
+  double blo[DIM], bhi[DIM];
+#pragma unroll
+  for (int c = 0; c < DIM; c++) {
+    blo[c] = fmin(fmin(s_blo[c][0], s_blo[c][1]), fmin(s_blo[c][2], s_blo[c][3]));
+    bhi[c] = fmax(fmax(s_bhi[c][0], s_bhi[c][1]), fmax(s_bhi[c][2], s_bhi[c][3]));
+  }
+  /* tiles within the cut-off of the box: one bit per tile */
+  const unsigned nmask = (ntiles + 63) / 64;
+  for (unsigned base = 0; base < ntiles; base += EV_THREADS) {
+    const unsigned t = base + tid;
+    bool keep = false;
+    if (t < ntiles) {
+      double d2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < DIM; c++) {
+        const double tl = tbox[(size_t)t * (2 * DIM) + 2 * c], th = tbox[(size_t)t * (2 * DIM) + 2 * c + 1];
+        const double g = fmax(0.0, fmax(tl - bhi[c], blo[c] - th));
+        d2 = fma(g, g, d2);
+      }
+      keep = d2 * coef > -72.0;
+    }
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
+    if (lane == 0 && (base / 64 + wave) < nmask) s_mask[base / 64 + wave] = b;
+  }
+  __syncthreads();
+
+  for (unsigned mi = 0; mi < nmask; mi++) {
+    unsigned long long mask = s_mask[mi];
+    while (mask) {
+      const unsigned t = mi * 64 + (unsigned)__builtin_ctzll(mask);
+      mask &= mask - 1;
+      const size_t c0 = (size_t)t * CT;
+      const int cnt = (int)((n - c0) < (size_t)CT ? (n - c0) : (size_t)CT);
+      __syncthreads();
+      for (int e = tid; e < cnt * (DIM + 1); e += EV_THREADS) s_c[e] = xs[c0 * (DIM + 1) + e];
+      __syncthreads();
+#pragma unroll 2
+      for (int e = 0; e < cnt; e++) {
+        double xc[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; c++) xc[c] = s_c[e * (DIM + 1) + c];
+        const double wj = s_c[e * (DIM + 1) + DIM];
+        double r2[TPT];
+        bool need = false;
+#pragma unroll
+        for (int tt = 0; tt < TPT; tt++) {
+          r2[tt] = 0.0;
+#pragma unroll
+          for (int c = 0; c < DIM; c++) { const double d = yy[tt][c] - xc[c]; r2[tt] = fma(d, d, r2[tt]); }
+          need |= (r2[tt] * coef > -72.0);
+        }
+        if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+#pragma unroll
+        for (int tt = 0; tt < TPT; tt++) acc[tt] = fma(wj, exp2_tbl(r2[tt] * coef, s_t0), acc[tt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TPT; t++)
+    if (kidx[t] < m) s[kidx[t]] = acc[t];
+}
+
+template <int TPT>
+static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x, size_t n, int dim, size_t xtda, const double *d_w,
+                            const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm)
+{
+  int *d_cperm = NULL;
+  int st = sinterp_sort_centres(ctx, d_x, n, xtda, dim, 8, &d_cperm);
+  if (st) return st;
+  const unsigned ntiles = (unsigned)((n + CT - 1) / CT);
+  void *buf = NULL;
+  st = sinterp_centbuf(ctx, (n * (size_t)(dim + 1) + (size_t)ntiles * 2 * dim) * sizeof(double), &buf);
+  if (st) return st;
+  double *xs = (double *)buf, *tbox = xs + n * (size_t)(dim + 1);
+  const size_t per_block = (size_t)EV_THREADS * TPT;
+  dim3 grid((unsigned)((m + per_block - 1) / per_block));
+  switch (dim) {
+    case 1:
+      hipLaunchKernelGGL((centre_pack_kernel<1>), dim3(ntiles), dim3(CT), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<1, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      break;
+    case 2:
+      hipLaunchKernelGGL((centre_pack_kernel<2>), dim3(ntiles), dim3(CT), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<2, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      break;
+    default:
+      hipLaunchKernelGGL((centre_pack_kernel<3>), dim3(ntiles), dim3(CT), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<3, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      break;
+  }
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------ */
 static double kernel_coef(int kind, double eps)
 {
   return kind == GSL_SINTERP_RBF_GAUSSIAN ? -(eps * eps) * 1.44269504088896340735992 : 0.5;
@@ -296,6 +467,10 @@ extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, doub
   }
   /* few targets: 1 per lane keeps more CUs busy; many: 2 per lane for ILP */
   const bool small = m < (size_t)EV_THREADS * 2 * 512;
+  static const bool no_cull = getenv("GSL_SINTERP_NO_CULL") && getenv("GSL_SINTERP_NO_CULL")[0] == '1';
+  if (kind == GSL_SINTERP_RBF_GAUSSIAN && d_perm && !no_cull && n >= 1024 && (n + CT - 1) / CT <= CULL_MAX_TILES)
+    return small ? launch_eval_cull<1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
+                 : launch_eval_cull<2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
   if (kind == GSL_SINTERP_RBF_GAUSSIAN)
     return small ? launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
                  : launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);

@@ -76,6 +76,8 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->d_inv) (void)hipFree(ctx->d_inv);
   if (ctx->d_sort) (void)hipFree(ctx->d_sort);
+  if (ctx->d_sort2) (void)hipFree(ctx->d_sort2);
+  if (ctx->d_cent) (void)hipFree(ctx->d_cent);
   if (ctx->d_sk_partial) (void)hipFree(ctx->d_sk_partial);
   if (ctx->d_sk_flags) (void)hipFree(ctx->d_sk_flags);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -250,6 +252,23 @@ int sinterp_sortbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out)
   *out = ctx->d_sort;
   return ST_SUCCESS;
 }
+
+static int grow_buf(gsl_sinterp_hip_ctx *ctx, void **buf, size_t *have, size_t bytes, void **out)
+{
+  if (bytes > *have) {
+    if (*buf) {
+      HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_OK(ctx, hipFree(*buf));
+      *buf = NULL; *have = 0;
+    }
+    HIP_OK(ctx, hipMalloc(buf, bytes));
+    *have = bytes;
+  }
+  *out = *buf;
+  return ST_SUCCESS;
+}
+int sinterp_sortbuf2(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out) { return grow_buf(ctx, &ctx->d_sort2, &ctx->sort2_bytes, bytes, out); }
+int sinterp_centbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out) { return grow_buf(ctx, &ctx->d_cent, &ctx->cent_bytes, bytes, out); }
 
 /* u(k) = (splitmix64(seed ^ k) >> 11) * 2^-53, out[i] = offset + span * u(first + i)
    (same generator as oracle/oracle_synth.c so CPU and GPU see

@@ -61,17 +61,26 @@ bbox_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, unsign
   }
 }
 
+/* g > 0: row-major cell index on a g^dim grid.  g < 0: Morton (bit-interleaved) index on a grid of
+   2^bits = -g cells per axis, so that runs of consecutive cells are spatially compact. */
 __device__ __forceinline__ unsigned cell_of(const double *__restrict__ y, size_t k, size_t ytda, int dim, int g,
                                             const unsigned long long *__restrict__ box)
 {
-  unsigned cell = 0;
+  const int gg = g < 0 ? -g : g;
+  unsigned cell = 0, ic[3] = {0, 0, 0};
   for (int c = dim - 1; c >= 0; c--) {
     const double lo = dunkey(box[2 * c]), hi = dunkey(box[2 * c + 1]);
     const double v = y[k * ytda + c];
     double f = (hi > lo) ? (v - lo) / (hi - lo) : 0.0;
-    int i = (f == f) ? (int)(f * g) : 0;           /* NaN coordinates go to cell 0 */
-    i = i < 0 ? 0 : (i >= g ? g - 1 : i);
-    cell = cell * (unsigned)g + (unsigned)i;
+    int i = (f == f) ? (int)(f * gg) : 0;          /* NaN coordinates go to cell 0 */
+    i = i < 0 ? 0 : (i >= gg ? gg - 1 : i);
+    ic[c] = (unsigned)i;
+    cell = cell * (unsigned)gg + (unsigned)i;
+  }
+  if (g < 0) {
+    cell = 0;
+    for (int b = 0; (1 << b) < gg; b++)
+      for (int c = 0; c < dim; c++) cell |= ((ic[c] >> b) & 1u) << (b * dim + c);
   }
   return cell;
 }
@@ -154,6 +163,57 @@ int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
                      (const unsigned long long *)box, cellid, count);
   hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, (unsigned)ncell);
   hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid, m, count, perm);
+  LAUNCH_CHECK(ctx);
+  *d_perm_out = perm;
+  return ST_SUCCESS;
+}
+
+/* after the scatter offset[c] is the END of cell c: order every cell's run by original index */
+__global__ void __launch_bounds__(256)
+cell_order_kernel(const unsigned *__restrict__ offset, unsigned ncell, int *__restrict__ perm)
+{
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const unsigned b = c ? offset[c - 1] : 0u, e = offset[c];
+  for (unsigned i = b + 1; i < e; i++) {
+    const int v = perm[i];
+    unsigned j = i;
+    while (j > b && perm[j - 1] > v) { perm[j] = perm[j - 1]; j--; }
+    perm[j] = v;
+  }
+}
+
+int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, size_t xtda, int dim, int per_cell,
+                         int **d_perm_out)
+{
+  *d_perm_out = NULL;
+  if (n == 0) return ST_SUCCESS;
+  if (n > 0x7fffffffULL) return sinterp_fail(ctx, ST_EINVAL, "sort_centres: more than 2^31 centres", hipSuccess, __FILE__, __LINE__);
+  const double cells = (double)n / (double)(per_cell > 0 ? per_cell : 8);
+  int g = 1;
+  const int gmax = dim == 1 ? (1 << 16) : (dim == 2 ? 512 : 64);
+  while (g < gmax && pow((double)(2 * g), dim) <= cells) g *= 2;      /* power of two per axis */
+  size_t ncell = 1;
+  for (int c = 0; c < dim; c++) ncell *= (size_t)g;
+  void *buf = NULL;
+  const size_t bytes = 64 + n * 4 + n * 4 + ncell * 4;
+  int st = sinterp_sortbuf2(ctx, bytes, &buf);
+  if (st) return st;
+  unsigned long long *box = (unsigned long long *)buf;
+  int *perm = (int *)((char *)buf + 64);
+  unsigned *cellid = (unsigned *)(perm + n);
+  unsigned *count = cellid + n;
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, box);
+  HIP_OK(ctx, hipMemsetAsync(count, 0, ncell * 4, ctx->stream));
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_x, n, xtda, dim, box);
+  hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_x, n, xtda, dim, -g,
+                     (const unsigned long long *)box, cellid, count);
+  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, (unsigned)ncell);
+  hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid, n, count, perm);
+  hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned *)count,
+                     (unsigned)ncell, perm);
   LAUNCH_CHECK(ctx);
   *d_perm_out = perm;
   return ST_SUCCESS;

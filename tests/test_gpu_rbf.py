@@ -124,3 +124,34 @@ def test_tps_solver_routes_agree(pkg, orc, dim, n, monkeypatch):
     # residual of the SPD-route weights against the true (unshifted) system
     phi = orc.rbf_fill(1, 0.0, x)
     assert np.abs(phi @ res["0"][1] - f).max() < 1e-9 * max(1.0, np.abs(f).max())
+
+
+@pytest.mark.parametrize("dim,n,m,eps_scale", [(3, 3000, 6000, 1.0), (2, 4096, 5000, 1.0), (1, 1500, 4100, 1.0),
+                                               (3, 1100, 4500, 0.05), (2, 2000, 4200, 4.0)])
+def test_gaussian_tile_culling_matches_oracle(pkg, orc, dim, n, m, eps_scale):
+    """The Gaussian sweep skips whole tiles of (Morton-ordered) centres whose bounding box is beyond
+    the 2^-72 cut-off of a workgroup's targets: same values as the oracle's full j-ascending sums
+    (<= 1e-10), for ragged tile counts, for wide kernels (nothing culled, eps_scale << 1), narrow ones,
+    and for targets far outside the cloud (everything culled -> exactly 0)."""
+    x = orc.synth_centres(n, dim)
+    eps = orc.gaussian_eps(n, dim) * eps_scale
+    rng = np.random.default_rng(n + m)
+    w = rng.standard_normal(n)
+    y = orc.synth_targets(0, m, dim)
+    y[-50:] += 40.0                                      # far away: every term < 2^-72
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_x, d_w, d_y = dev(x), dev(w), dev(y)
+    d_s = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
+    ctx.rbf_eval(0, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), m, dim, ptr(d_s))
+    ctx.sync()
+    got = d_s.cpu().numpy()
+    want = orc.rbf_eval(0, eps, x, w, y)
+    assert relerr(got, want) < TOL
+    assert (got[-50:] == 0.0).all()
+    # run to run: the centre (summation) order is fixed; which negligible (< 2^-72 |w_j|) terms a target
+    # also receives depends on its wave-mates, whose grouping comes from an atomic scatter -> results
+    # agree to the dropped-term bound N * 2^-72 * max|w|, not necessarily to the last bit of tiny values
+    d_s2 = torch.empty(m, dtype=torch.float64, device="cuda")
+    ctx.rbf_eval(0, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), m, dim, ptr(d_s2))
+    ctx.sync()
+    assert np.abs(got - d_s2.cpu().numpy()).max() <= n * 2.0 ** -72 * np.abs(w).max()
