@@ -223,8 +223,7 @@ def time_top_gemm(pkg, ctx, n, reps=3):
     for _ in range(reps):
         ctx.gemm_minus(h, h, h, a.data_ptr(), h, a.data_ptr(), h, 0, c.data_ptr(), h, 1)
     ms = ctx.timer_stop() / reps
-    tiles = h // 128
-    flops = 2.0 * 128 * 128 * h * (tiles * (tiles + 1) // 2)        # launched (lower-trapezoid) tiles only
+    flops = 2.0 * h * (h * (h + 1) / 2.0)                           # algorithmic: the lower triangle incl. diagonal, K = h
     return {"h": h, "ms": ms, "tflops": flops / ms / 1e9}
 
 
@@ -248,16 +247,28 @@ def rooflines(cfg, n, dim, m_rank, ph, dominant, extra=None, gemm=None, pmc=None
     by = (8.0 * dim + 8.0) * m_rank
     r_gemm = None
     if gemm:
-        r_gemm = {"kernel": "gemm_minus_streamk_kernel (top-level trailing update, %d^3 lower)" % gemm["h"],
+        r_gemm = {"kernel": "gemm_minus_streamk_kernel<256,128,64,64> (top-level trailing update, %d^3 lower)" % gemm["h"],
                   "bound": "mfma", "achieved": round(gemm["tflops"], 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(gemm["tflops"] / FP64_PEAK_TFLOPS, 5), "launch_ms": round(gemm["ms"], 4),
                   "traffic": pmc.get("gemm_minus_streamk_kernel")}
     pair_ops = n * m_rank
-    r_eval = {"kernel": "rbf_eval_kernel", "bound": "hbm", "achieved": round(by / te / 1e9, 3), "peak": HBM_PEAK_GBS,
-              "unit": "GB/s", "frac": round(by / te / 1e9 / HBM_PEAK_GBS, 6), "traffic": pmc.get("rbf_eval_kernel"),
+    gauss = cfg["kind"] == "gaussian"
+    ek = "rbf_eval_gauss_cull_kernel" if gauss else "rbf_eval_kernel"
+    r_eval = {"kernel": ek, "bound": "hbm", "achieved": round(by / te / 1e9, 3), "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": round(by / te / 1e9 / HBM_PEAK_GBS, 6), "traffic": pmc.get(ek),
               "pair_evals_per_s": round(pair_ops / te, 1),
               "note": "fp64-VALU bound by construction (N pair-evals per 8d+8 B): the HBM fraction is ~1e-3; "
                       "pair_evals_per_s is the meaningful rate"}
+    if gauss:
+        r_eval["note"] += ("; Gaussian: tiles of centres beyond the 2^-72 cut-off are culled, so the algorithmic "
+                           "pair rate (N*M/t) exceeds what the VALUs could evaluate pair by pair")
+    else:
+        # thin-plate sweep: ~20 VALU instructions per pair (2-D; ISA count of the inner loop), issue peak =
+        # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-instructions/s
+        ipp = 17 + 3 * (dim - 1)
+        peak = 256 * 4 * 16 * 2.4e9
+        r_eval["valu_issue"] = {"instr_per_pair": ipp, "achieved_lane_instr_per_s": round(pair_ops * ipp / te, 1),
+                                "peak_lane_instr_per_s": peak, "frac": round(pair_ops * ipp / te / peak, 4)}
     # dominant single kernel: the GEMM when the factorisation (mostly GEMM) outweighs the sweep
     gemm_dominant = r_gemm is not None and 0.55 * tf > te
     res["roofline"] = r_gemm if gemm_dominant else r_eval
