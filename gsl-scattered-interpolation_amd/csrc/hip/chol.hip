@@ -1009,13 +1009,13 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
 }
 
 static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout,
-                         size_t ldb, int nrhs, int mode, int unit, double *d_inv)
+                         size_t ldb, int nrhs, int mode, int unit, double *d_inv, int inv_ready)
 {
   const size_t nblk = (n + TS - 1) / TS;
   /* single-block systems keep the exact substitution of the reference (cblas/source_trsv_r.h);
      larger ones multiply by the inverted 64x64 diagonal blocks */
   const bool use_inv = nblk > 1 && d_inv != NULL;
-  if (use_inv) {
+  if (use_inv && !inv_ready) {
     hipLaunchKernelGGL(tri_inv_kernel, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, T, ldt, n, mode == 2 ? 1 : 0, unit, d_inv);
     LAUNCH_CHECK(ctx);
   }
@@ -1046,14 +1046,16 @@ static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
   return ST_SUCCESS;
 }
 
-int sinterp_trsv_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, size_t ldb,
-                       int nrhs, int mode, int unit)
+/* inv_ready: the inverted diagonal blocks of this very triangle are still in the context's buffer
+   (the backward sweep of a Cholesky solve right after its forward sweep) */
+static int trsv_multi_ex(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, size_t ldb,
+                         int nrhs, int mode, int unit, int inv_ready)
 {
   if (n == 0 || nrhs == 0) return ST_SUCCESS;
   if (nrhs > TRSV_MAXR) return sinterp_fail(ctx, ST_EINVAL, "trsv: too many right-hand sides", hipSuccess, __FILE__, __LINE__);
   /* one cached graph per direction: slot 2 forward, slot 3 backward */
   const int slot = mode == 0 ? 2 : 3;
-  const size_t key_lda = ((ldt * 8 + (size_t)mode * 2 + (size_t)unit) * 8 + (size_t)nrhs) ^ (ldb << 40);
+  const size_t key_lda = ((ldt * 8 + (size_t)mode * 2 + (size_t)unit) * 8 + (size_t)nrhs) ^ (ldb << 40) ^ ((size_t)inv_ready << 62);
   const void *p1 = (const void *)((uintptr_t)b ^ ((uintptr_t)xout << 1));
   int replayed = 0;
   int st = sinterp_graph_try_launch(ctx, slot, n, key_lda, T, p1, &replayed);
@@ -1066,9 +1068,15 @@ int sinterp_trsv_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size
   hipStream_t saved;
   st = sinterp_capture_begin(ctx, &saved);
   if (st) return st;
-  st = trsv_launches(ctx, n, T, ldt, b, xout, ldb, nrhs, mode, unit, (double *)d_inv);
+  st = trsv_launches(ctx, n, T, ldt, b, xout, ldb, nrhs, mode, unit, (double *)d_inv, inv_ready);
   int st2 = sinterp_capture_end(ctx, saved, slot, n, key_lda, T, p1);
   return st ? st : st2;
+}
+
+int sinterp_trsv_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, size_t ldb,
+                       int nrhs, int mode, int unit)
+{
+  return trsv_multi_ex(ctx, n, T, ldt, b, xout, ldb, nrhs, mode, unit, 0);
 }
 
 int sinterp_trsv(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, int mode,
@@ -1086,7 +1094,7 @@ int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double 
   if (st) return st;
   st = sinterp_trsv_multi(ctx, n, d_llt, lda, d_x, (double *)d_tmp, ldx, nrhs, 0, 0);   /* L c = b     (cholesky.c:178) */
   if (st) return st;
-  return sinterp_trsv_multi(ctx, n, d_llt, lda, (double *)d_tmp, d_x, ldx, nrhs, 1, 0); /* L^T x = c   (cholesky.c:181) */
+  return trsv_multi_ex(ctx, n, d_llt, lda, (double *)d_tmp, d_x, ldx, nrhs, 1, 0, 1);   /* L^T x = c   (cholesky.c:181); same inverted blocks */
 }
 
 extern "C" int gsl_sinterp_hip_cholesky_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda, double *d_x)

@@ -9,7 +9,8 @@
  * Outputs are written back at the original positions: the caller-visible layout is unchanged.
  *
  * Four small kernels: bounding box (atomic min/max on order-preserving integer keys),
- * histogram, exclusive scan (one workgroup), scatter.  ~1 ms for 10^7 targets.
+ * histogram (one atomic per point, its return value is the point's slot in the cell),
+ * exclusive scan (one workgroup), atomic-free scatter.
  */
 #include "common.h"
 #include <math.h>
@@ -85,19 +86,23 @@ __device__ __forceinline__ unsigned cell_of(const double *__restrict__ y, size_t
   return cell;
 }
 
+/* one atomic per point: the returned old count is the point's slot inside its cell, so the scatter
+   pass needs no atomics */
 __global__ void __launch_bounds__(256)
 cell_hist_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, int g, const unsigned long long *__restrict__ box,
-                 unsigned *__restrict__ cellid, unsigned *__restrict__ count)
+                 unsigned *__restrict__ cellid, unsigned *__restrict__ slot, unsigned *__restrict__ count)
 {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
     const unsigned c = cell_of(y, k, ytda, dim, g, box);
     cellid[k] = c;
-    atomicAdd(&count[c], 1u);
+    slot[k] = atomicAdd(&count[c], 1u);
   }
 }
 
-/* in-place exclusive scan of count[0..ncell) by one workgroup */
+/* in-place exclusive scan of count[0..ncell) by one workgroup, 8 consecutive entries per thread and
+   pass; count[ncell] receives the total */
+#define SCAN_PER 8
 __global__ void __launch_bounds__(1024)
 cell_scan_kernel(unsigned *__restrict__ count, unsigned ncell)
 {
@@ -106,31 +111,35 @@ cell_scan_kernel(unsigned *__restrict__ count, unsigned ncell)
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (unsigned base = 0; base < ncell; base += 1024) {
-    const unsigned i = base + threadIdx.x;
-    const unsigned v = i < ncell ? count[i] : 0u;
-    unsigned incl = v;
+  for (unsigned base = 0; base < ncell; base += 1024 * SCAN_PER) {
+    const unsigned i0 = base + threadIdx.x * SCAN_PER;
+    unsigned v[SCAN_PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER; q++) { v[q] = (i0 + q < ncell) ? count[i0 + q] : 0u; sum += v[q]; }
+    unsigned incl = sum;
     for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(incl, off); if (lane >= off) incl += t; }
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     unsigned woff = 0;
     for (int w = 0; w < wave; w++) woff += s_wave[w];
     const unsigned carry = s_carry;
-    if (i < ncell) count[i] = carry + woff + incl - v;
+    unsigned run = carry + woff + incl - sum;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER; q++) { if (i0 + q < ncell) count[i0 + q] = run; run += v[q]; }
     __syncthreads();
     if (threadIdx.x == 1023) s_carry = carry + woff + incl;
     __syncthreads();
   }
+  if (threadIdx.x == 0) count[ncell] = s_carry;
 }
 
 __global__ void __launch_bounds__(256)
-cell_scatter_kernel(const unsigned *__restrict__ cellid, size_t m, unsigned *__restrict__ offset, int *__restrict__ perm)
+cell_scatter_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ slot, size_t m,
+                    const unsigned *__restrict__ offset, int *__restrict__ perm)
 {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
-    const unsigned pos = atomicAdd(&offset[cellid[k]], 1u);
-    perm[pos] = (int)k;
-  }
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride)
+    perm[offset[cellid[k]] + slot[k]] = (int)k;
 }
 
 /* perm[i] = index of the i-th target in cell order.  Targets per cell ~ `per_cell`. */
@@ -147,34 +156,36 @@ int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   size_t ncell = 1;
   for (int c = 0; c < dim; c++) ncell *= (size_t)g;
   void *buf = NULL;
-  const size_t bytes = 64 + m * 4 /*perm*/ + m * 4 /*cellid*/ + ncell * 4;
+  const size_t bytes = 64 + m * 4 /*perm*/ + m * 4 /*cellid*/ + m * 4 /*slot*/ + (ncell + 1) * 4;
   int st = sinterp_sortbuf(ctx, bytes, &buf);
   if (st) return st;
   unsigned long long *box = (unsigned long long *)buf;
   int *perm = (int *)((char *)buf + 64);
   unsigned *cellid = (unsigned *)(perm + m);
-  unsigned *count = cellid + m;
+  unsigned *slot = cellid + m;
+  unsigned *count = slot + m;
   hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, box);   /* no host-sourced async copy */
   HIP_OK(ctx, hipMemsetAsync(count, 0, ncell * 4, ctx->stream));
   size_t blocks = (m + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, box);
   hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g,
-                     (const unsigned long long *)box, cellid, count);
+                     (const unsigned long long *)box, cellid, slot, count);
   hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, (unsigned)ncell);
-  hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid, m, count, perm);
+  hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid,
+                     (const unsigned *)slot, m, (const unsigned *)count, perm);
   LAUNCH_CHECK(ctx);
   *d_perm_out = perm;
   return ST_SUCCESS;
 }
 
-/* after the scatter offset[c] is the END of cell c: order every cell's run by original index */
+/* cell c occupies perm[offset[c] .. offset[c+1]): order every cell's run by original index */
 __global__ void __launch_bounds__(256)
 cell_order_kernel(const unsigned *__restrict__ offset, unsigned ncell, int *__restrict__ perm)
 {
   const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncell) return;
-  const unsigned b = c ? offset[c - 1] : 0u, e = offset[c];
+  const unsigned b = offset[c], e = offset[c + 1];
   for (unsigned i = b + 1; i < e; i++) {
     const int v = perm[i];
     unsigned j = i;
@@ -196,22 +207,24 @@ int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, 
   size_t ncell = 1;
   for (int c = 0; c < dim; c++) ncell *= (size_t)g;
   void *buf = NULL;
-  const size_t bytes = 64 + n * 4 + n * 4 + ncell * 4;
+  const size_t bytes = 64 + n * 4 + n * 4 + n * 4 + (ncell + 1) * 4;
   int st = sinterp_sortbuf2(ctx, bytes, &buf);
   if (st) return st;
   unsigned long long *box = (unsigned long long *)buf;
   int *perm = (int *)((char *)buf + 64);
   unsigned *cellid = (unsigned *)(perm + n);
-  unsigned *count = cellid + n;
+  unsigned *slot = cellid + n;
+  unsigned *count = slot + n;
   hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, box);
   HIP_OK(ctx, hipMemsetAsync(count, 0, ncell * 4, ctx->stream));
   size_t blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_x, n, xtda, dim, box);
   hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_x, n, xtda, dim, -g,
-                     (const unsigned long long *)box, cellid, count);
+                     (const unsigned long long *)box, cellid, slot, count);
   hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, (unsigned)ncell);
-  hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid, n, count, perm);
+  hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid,
+                     (const unsigned *)slot, n, (const unsigned *)count, perm);
   hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned *)count,
                      (unsigned)ncell, perm);
   LAUNCH_CHECK(ctx);
