@@ -186,21 +186,35 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
       int best = 0, next = -1;
       double best_worst = -1;
       NodeRec nrec = cur;
-      for (int i = 0; i < nc; i++) {
-        const int ch = cur.child[i];
-        bool hit = false;
-        if (ch > 0 && ch < n_nodes) {
-          NodeRec cr = load_rec(rec, ch);
-          if (!META_SINGULAR(cr.meta)) { solve_node(cr, y0, y1, s0, s1, c0, c1); hit = inside_unit(c0, c1); }
-          if (hit) { next = ch; nrec = cr; break; }
-        }
-        double worst = violation(c0, c1);
-        if ((best_worst < 0) || (worst < best_worst)) { best_worst = worst; best = i; }
+      /* The walk is a chain of dependent gathers (latency bound, ~0.7 TB/s of 64-byte records): all
+         children's records are requested at once, then TESTED in the reference's order -- the first
+         containing child wins and later ones are not evaluated, so the persistent coordinates and
+         the fallback see exactly the reference's sequence of operations. */
+      const int ch0 = cur.child[0], ch1 = cur.child[1], ch2 = cur.child[2];
+      const bool v0 = nc > 0 && ch0 > 0 && ch0 < n_nodes, v1 = nc > 1 && ch1 > 0 && ch1 < n_nodes,
+                 v2 = nc > 2 && ch2 > 0 && ch2 < n_nodes;
+      const NodeRec cr0 = load_rec(rec, v0 ? ch0 : 0), cr1 = load_rec(rec, v1 ? ch1 : 0), cr2 = load_rec(rec, v2 ? ch2 : 0);
+      /* (named records, not an array: an indexed array of structs ends up in scratch memory) */
+#define BARY_TEST_CHILD(I, CR, VALID, CH)                                                            \
+      if ((I) < nc && next < 0) {                                                                     \
+        bool hit = false;                                                                             \
+        if (VALID) {                                                                                  \
+          if (!META_SINGULAR((CR).meta)) { solve_node(CR, y0, y1, s0, s1, c0, c1); hit = inside_unit(c0, c1); } \
+          if (hit) { next = (CH); nrec = (CR); }                                                      \
+        }                                                                                             \
+        if (!hit) {                                                                                   \
+          const double worst = violation(c0, c1);                                                     \
+          if ((best_worst < 0) || (worst < best_worst)) { best_worst = worst; best = (I); }           \
+        }                                                                                             \
       }
+      BARY_TEST_CHILD(0, cr0, v0, ch0)
+      BARY_TEST_CHILD(1, cr1, v1, ch1)
+      BARY_TEST_CHILD(2, cr2, v2, ch2)
+#undef BARY_TEST_CHILD
       if (next < 0) {                                   /* rounding fallback, linear_simplex.c:398-400 */
-        next = cur.child[best];
+        next = best == 0 ? ch0 : (best == 1 ? ch1 : ch2);
         if (next <= 0 || next >= n_nodes) break;
-        nrec = load_rec(rec, next);
+        nrec = best == 0 ? cr0 : (best == 1 ? cr1 : cr2);
       }
       node = next;
       cur = nrec;
