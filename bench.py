@@ -182,6 +182,28 @@ def main():
     # ---- sanity of the result that was just produced (not timed)
     sample = d_s[: min(m_rank, 4096)].cpu().numpy()
     assert np.isfinite(sample).all(), "non-finite interpolated values"
+    verify = None
+    if cfg["kind"] != "bary":
+        # the weights of the LAST timed step must interpolate the data: s(x_i) = f_i at a sample of the
+        # centres (catches a step that ran fast because it computed garbage, e.g. a broken graph replay)
+        ns = min(n, 2048)
+        d_chk = torch.empty(ns, dtype=f64, device="cuda")
+        ctx.rbf_eval(kind, eps, d_x.data_ptr(), n, dim, dim, d_w.data_ptr(), d_x.data_ptr(), ns, dim, d_chk.data_ptr())
+        torch.cuda.synchronize()
+        verify = float((d_chk - d_f[:ns]).abs().max()) / float(d_f.abs().max())
+        assert verify < 1e-6, f"interpolant does not reproduce the data after the timed steps: {verify:.3e}"
+    else:
+        # barycentric: the first values of this rank's shard against the library's host per-point entries
+        # (find_leaf + interp_point; the reference's own API, bit-identical to the oracle per tests/test_host_tree.py)
+        nchk = 300
+        yh = d_y[:nchk].cpu().numpy()
+        got_v, got_l = d_s[:nchk].cpu().numpy(), d_leaf[:nchk].cpu().numpy()
+        bad = 0
+        for i in range(nchk):
+            leaf = tree.find_leaf(yh[i])
+            bad += int(leaf != got_l[i] or tree.interp_point(leaf, fh, yh[i]) != got_v[i])
+        verify = float(bad)
+        assert bad == 0, f"{bad} of {nchk} GPU barycentric results differ from the host walk"
 
     if rank == 0:
         out = {
@@ -194,6 +216,7 @@ def main():
                        "targets_per_gpu": m_rank, "targets_total": m_total,
                        "parallelism": f"target shards x{world}, weights broadcast (RCCL)" if world > 1 else "1 GPU"},
             "phase_ms": {k: round(v, 4) for k, v in ph_ms.items()},
+            "verify_after_timed_steps": verify,
         }
         gemm = time_top_gemm(pkg, ctx, n) if cfg["kind"] != "bary" else None
         pmc = {}

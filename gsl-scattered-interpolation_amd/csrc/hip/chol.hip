@@ -572,6 +572,8 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
   return join_pend(ctx, &mine);
 }
 
+__global__ void chol_zero_info_kernel(int *info) { *info = 0; }
+
 extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
@@ -593,7 +595,10 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
     hipStream_t saved;
     st = sinterp_capture_begin(ctx, &saved);
     if (st) return st;
-    hipError_t me = hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream);
+    /* a kernel, not a memset node: a memset node inside a replayed graph was observed not to be
+       ordered/visible like the kernels around it (stale flags on the second launch of a sweep graph) */
+    hipLaunchKernelGGL(chol_zero_info_kernel, dim3(1), dim3(1), 0, ctx->stream, d_info);
+    hipError_t me = hipSuccess;
     const unsigned nt = (unsigned)((n + 31) / 32);
     hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
     ctx->la_events_used = 0;
@@ -601,7 +606,7 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
     hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
                        (const double *)d_diag);
     int st2 = sinterp_capture_end(ctx, saved, 0, n, lda, d_a, NULL);
-    if (me != hipSuccess) return sinterp_fail(ctx, ST_EFAILED, "hipMemsetAsync", me, __FILE__, __LINE__);
+    if (me != hipSuccess) return sinterp_fail(ctx, ST_EFAILED, "zero info", me, __FILE__, __LINE__);
     if (st) return st;
     if (st2) return st2;
     LAUNCH_CHECK(ctx);
@@ -890,8 +895,12 @@ trsv_sweep_inv_kernel(const double *__restrict__ T, size_t ldt, size_t n, double
    the sweep order, which belong to workgroups dispatched before it: no deadlock.  b is read only. */
 __global__ void __launch_bounds__(256)
 trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const double *__restrict__ b, double *xout, size_t ldb,
-                     int nrhs, int mode, const double *__restrict__ Dinv, unsigned *flags, unsigned nblk)
+                     int nrhs, int mode, const double *__restrict__ Dinv, unsigned *tf, unsigned nblk)
 {
+  /* tf[0] is stable for the whole launch: only the workgroup of the LAST block of the sweep advances it,
+     after every other block has been published (it has consumed them all) */
+  unsigned *flags = tf + 1;
+  const unsigned want = __hip_atomic_load(tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   __shared__ double sx[2][TRSV_MAXR][TS];
   __shared__ double sW[TS][TS + 1];
   __shared__ double srhs[TRSV_MAXR][TS];
@@ -936,7 +945,7 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
       const int buf = sstep & 1;
       for (int e = tid; e < nrhs * TS; e += 256) {        /* nrhs can be 5: more entries than threads */
         const int r = e / TS, c = e % TS;
-        while (__hip_atomic_load(flags + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(flags + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
         sx[buf][r][c] = (j0 + c < n) ? __hip_atomic_load(xout + r * ldb + j0 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       }
       __syncthreads();
@@ -1004,7 +1013,10 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flags + I, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      __hip_atomic_store(flags + I, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == nblk - 1) __hip_atomic_store(tf, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* sweep complete */
+    }
   }
 }
 
@@ -1020,12 +1032,10 @@ static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
     LAUNCH_CHECK(ctx);
   }
   static const bool no_df = getenv("GSL_SINTERP_NO_DATAFLOW_TRSV") && getenv("GSL_SINTERP_NO_DATAFLOW_TRSV")[0] == '1';
-  if (use_inv && !no_df && ctx->sk_wgs > 0) {
-    unsigned *d_flags = (unsigned *)(d_inv + nblk * TS * TS);
-    HIP_OK(ctx, hipMemsetAsync(d_flags, 0, nblk * sizeof(unsigned), ctx->stream));
+  if (use_inv && !no_df && ctx->sk_wgs > 0 && ctx->d_tf && ctx->tf_count >= nblk + 1) {
     const unsigned G = (unsigned)(nblk < (size_t)ctx->sk_wgs ? nblk : (size_t)ctx->sk_wgs);
     hipLaunchKernelGGL(trsv_dataflow_kernel, dim3(G), dim3(256), 0, ctx->stream, T, ldt, n, (const double *)b, xout, ldb, nrhs, mode,
-                       (const double *)d_inv, d_flags, (unsigned)nblk);
+                       (const double *)d_inv, ctx->d_tf, (unsigned)nblk);
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }
@@ -1061,8 +1071,23 @@ static int trsv_multi_ex(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
   int st = sinterp_graph_try_launch(ctx, slot, n, key_lda, T, p1, &replayed);
   if (st || replayed) return st;
   void *d_inv = NULL;
-  st = sinterp_invbuf(ctx, ((n + TS - 1) / TS) * (TS * TS * sizeof(double) + sizeof(unsigned)), &d_inv);   /* inverses + flags */
+  st = sinterp_invbuf(ctx, ((n + TS - 1) / TS) * TS * TS * sizeof(double), &d_inv);
   if (st) return st;
+  {
+    /* epoch + per-block flags of the dataflow sweep: grown (and zeroed) outside capture only */
+    const size_t need = (n + TS - 1) / TS + 1;
+    if (need > ctx->tf_count) {
+      HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_tf) { HIP_OK(ctx, hipFree(ctx->d_tf)); ctx->d_tf = NULL; ctx->tf_count = 0; }
+      const size_t cnt = need < 1024 ? 1024 : need * 2;
+      HIP_OK(ctx, hipMalloc((void **)&ctx->d_tf, cnt * sizeof(unsigned)));
+      HIP_OK(ctx, hipMemset(ctx->d_tf, 0, cnt * sizeof(unsigned)));
+      HIP_OK(ctx, hipDeviceSynchronize());
+      ctx->tf_count = cnt;
+      for (int i = 2; i < 4; i++)                       /* cached sweep graphs hold the old pointer */
+        if (ctx->graph[i].exec) { (void)hipGraphExecDestroy(ctx->graph[i].exec); ctx->graph[i].exec = NULL; }
+    }
+  }
   st = sinterp_streamk_prepare(ctx);                   /* CU count (the dataflow sweep needs co-resident workgroups) */
   if (st) return st;
   hipStream_t saved;

@@ -45,6 +45,11 @@ struct gsl_sinterp_hip_ctx {
   double *d_sk_partial;
   unsigned *d_sk_flags;
   int sk_wgs;               /* persistent workgroups = CUs of the device; 0 = not prepared */
+  /* dataflow sweeps (chol.hip): [0] = epoch of the last completed sweep, [1 + J] = epoch in which
+     block J was last published.  Never reset (no memset node in the captured graphs): a sweep
+     publishes with epoch + 1 and its last block advances the epoch. */
+  unsigned *d_tf;
+  size_t tf_count;
   char err[512];
 };
 

@@ -192,3 +192,33 @@ def test_single_launch_sweeps_more_blocks_than_cus(pkg, n):
     ctx.cholesky_svx(n, ptr(L), n, ptr(d_x))            # raises on a non-zero status
     ctx.sync()
     assert float((d_x - xs).abs().max()) <= 1e-11 * float(xs.abs().max())
+
+
+@pytest.mark.gpu
+def test_graph_replays_are_correct(pkg, orc):
+    """The factorisation and sweep launch sequences are captured into hipGraphs on first use and
+    REPLAYED afterwards: repeated calls on one context (same buffers) must give the same answers --
+    including the failure flag, which a replay has to reset -- bit for bit."""
+    n = 1024
+    a = spd(n, 3)
+    bad = a.copy(); bad[700, 700] = -1.0
+    b = np.cos(np.arange(n))
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_a = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    d_x = torch.empty(n, dtype=torch.float64, device="cuda")
+    results = []
+    for rep, mat in enumerate([a, bad, a, a, bad, a]):
+        d_a.copy_(dev(mat))
+        st, info = ctx.cholesky_decomp1(n, ptr(d_a), n)
+        if mat is bad:
+            assert st == pkg.capi.GSL_EDOM and info == 701
+            continue
+        assert st == 0 and info == 0
+        d_x.copy_(dev(b))
+        ctx.cholesky_svx(n, ptr(d_a), n, ptr(d_x))
+        ctx.sync()
+        results.append(d_x.cpu().numpy())
+    xo = orc.cholesky_solve(orc.cholesky_decomp1(a)[1], b)
+    assert np.abs(results[0] - xo).max() <= 1e-11 * np.abs(xo).max()
+    for r in results[1:]:
+        assert np.array_equal(r, results[0])
