@@ -913,6 +913,14 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
     const int nbI = (int)((n - i0) < TS ? (n - i0) : TS);
     __syncthreads();                                     /* previous block of this workgroup fully done with LDS */
     for (int e = tid; e < TS * TS; e += 256) sW[e / TS][e % TS] = Dinv[(size_t)I * (TS * TS) + e];
+    /* this block's right-hand side, fetched now: it is only needed after the last x_J has arrived, and
+       a load issued there would sit on the critical path of the whole sweep */
+    double bpre[(TRSV_MAXR * TS + 255) / 256];
+#pragma unroll
+    for (int q = 0; q < (TRSV_MAXR * TS + 255) / 256; q++) {
+      const int e = q * 256 + tid, r = e / TS, c = e % TS;
+      bpre[q] = (e < nrhs * TS && c < nbI) ? b[r * ldb + i0 + c] : 0.0;
+    }
     double acc[TRSV_MAXR][2];
 #pragma unroll
     for (int r = 0; r < TRSV_MAXR; r++) acc[r][0] = acc[r][1] = 0.0;
@@ -972,10 +980,13 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
 #pragma unroll
       for (int r = 0; r < TRSV_MAXR; r++) if (r < nrhs) s_part[r][wave][lane] = acc[r][0];
       __syncthreads();
-      for (int e = tid; e < nrhs * TS; e += 256) {
-        const int r = e / TS, c = e % TS;
-        const double sum = (s_part[r][0][c] + s_part[r][1][c]) + (s_part[r][2][c] + s_part[r][3][c]);
-        srhs[r][c] = (c < nbI) ? b[r * ldb + i0 + c] - sum : 0.0;
+#pragma unroll
+      for (int q = 0; q < (TRSV_MAXR * TS + 255) / 256; q++) {
+        const int e = q * 256 + tid, r = e / TS, c = e % TS;
+        if (e < nrhs * TS) {
+          const double sum = (s_part[r][0][c] + s_part[r][1][c]) + (s_part[r][2][c] + s_part[r][3][c]);
+          srhs[r][c] = (c < nbI) ? bpre[q] - sum : 0.0;
+        }
       }
     } else {
 #pragma unroll
@@ -988,9 +999,15 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
             a += __shfl_xor(a, 2);
             a += __shfl_xor(a, 4);
             const int row = pass * 32 + wave * 8 + rsub;
-            if ((lane & 7) == 0) srhs[r][row] = (row < nbI) ? b[r * ldb + i0 + row] - a : 0.0;
+            if ((lane & 7) == 0) srhs[r][row] = -a;
           }
         }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < (TRSV_MAXR * TS + 255) / 256; q++) {
+        const int e = q * 256 + tid, r = e / TS, c = e % TS;
+        if (e < nrhs * TS) srhs[r][c] = (c < nbI) ? bpre[q] + srhs[r][c] : 0.0;
+      }
     }
     __syncthreads();
     /* x_I = W srhs  (W = Dinv for the forward sweep, Dinv^T for the backward ones) */
