@@ -574,7 +574,9 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
 
 __global__ void chol_zero_info_kernel(int *info) { *info = 0; }
 
-extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info)
+/* symmetric_input: both triangles of d_a hold the matrix (the RBF fill writes it that way), so the
+   copy that preserves the original in the strict upper triangle (cholesky.c:103) is already there */
+static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, bool symmetric_input)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   REQUIRE(ctx, lda >= n, ST_EINVAL);
@@ -589,7 +591,8 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
   st = sinterp_streamk_prepare(ctx);
   if (st) return st;
   int replayed = 0;
-  st = sinterp_graph_try_launch(ctx, 0, n, lda, d_a, NULL, &replayed);
+  const void *gkey = symmetric_input ? (const void *)(uintptr_t)1 : NULL;
+  st = sinterp_graph_try_launch(ctx, 0, n, lda, d_a, gkey, &replayed);
   if (st) return st;
   if (!replayed) {
     hipStream_t saved;
@@ -600,12 +603,12 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
     hipLaunchKernelGGL(chol_zero_info_kernel, dim3(1), dim3(1), 0, ctx->stream, d_info);
     hipError_t me = hipSuccess;
     const unsigned nt = (unsigned)((n + 31) / 32);
-    hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
+    if (!symmetric_input) hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
     ctx->la_events_used = 0;
     st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag, 0, NULL);
     hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
                        (const double *)d_diag);
-    int st2 = sinterp_capture_end(ctx, saved, 0, n, lda, d_a, NULL);
+    int st2 = sinterp_capture_end(ctx, saved, 0, n, lda, d_a, gkey);
     if (me != hipSuccess) return sinterp_fail(ctx, ST_EFAILED, "zero info", me, __FILE__, __LINE__);
     if (st) return st;
     if (st2) return st2;
@@ -621,6 +624,16 @@ extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t
     return ST_EDOM;
   }
   return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info)
+{
+  return cholesky_decomp1_impl(ctx, n, d_a, lda, h_info, false);
+}
+
+int sinterp_cholesky_decomp1_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info)
+{
+  return cholesky_decomp1_impl(ctx, n, d_a, lda, h_info, true);
 }
 
 /* ------------------------------------------------------------------------ */

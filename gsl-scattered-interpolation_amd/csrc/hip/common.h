@@ -110,6 +110,8 @@ int sinterp_trsv_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size
                        int nrhs, int mode, int unit);
 int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda, double *d_x, size_t ldx,
                                int nrhs);
+/* gsl_sinterp_hip_cholesky_decomp1 for an input that is stored symmetrically (both triangles valid) */
+int sinterp_cholesky_decomp1_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info);
 /* second grow-only buffer for vectors that must outlive factorisation workspaces */
 int sinterp_aux(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 int sinterp_invbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);

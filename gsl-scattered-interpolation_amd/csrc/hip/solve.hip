@@ -152,7 +152,7 @@ extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, dou
   int info = 0;
 
   if (kind == GSL_SINTERP_RBF_GAUSSIAN) {
-    st = gsl_sinterp_hip_cholesky_decomp1(ctx, n, d_phi, lda, &info);
+    st = sinterp_cholesky_decomp1_sym(ctx, n, d_phi, lda, &info);   /* the fill (and the shift) write both triangles */
     if (st) return st;
     if (h_route) *h_route = 1;
     return gsl_sinterp_hip_cholesky_svx(ctx, n, d_phi, lda, d_w);
@@ -181,7 +181,7 @@ extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, dou
     hipLaunchKernelGGL(poly_shift_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, d_phi, lda, n,
                        (const double *)Pk, k, cmul, (const unsigned long long *)d_norm);
     LAUNCH_CHECK(ctx);
-    st = gsl_sinterp_hip_cholesky_decomp1(ctx, n, d_phi, lda, &info);
+    st = sinterp_cholesky_decomp1_sym(ctx, n, d_phi, lda, &info);   /* the fill (and the shift) write both triangles */
     if (st == ST_EDOM) continue;                  /* not SPD with this shift: larger shift, then LU */
     if (st) return st;
     st = sinterp_cholesky_svx_multi(ctx, n, d_phi, lda, Y, n, k + 1);
