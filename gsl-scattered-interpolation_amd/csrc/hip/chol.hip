@@ -908,12 +908,16 @@ trsv_sweep_inv_kernel(const double *__restrict__ T, size_t ldt, size_t n, double
    the sweep order, which belong to workgroups dispatched before it: no deadlock.  b is read only. */
 __global__ void __launch_bounds__(256)
 trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const double *__restrict__ b, double *xout, size_t ldb,
-                     int nrhs, int mode, const double *__restrict__ Dinv, unsigned *tf, unsigned nblk)
+                     int nrhs, int mode, const double *__restrict__ Dinv, unsigned *tf, unsigned long long *xq, unsigned nblk)
 {
   /* tf[0] is stable for the whole launch: only the workgroup of the LAST block of the sweep advances it,
-     after every other block has been published (it has consumed them all) */
-  unsigned *flags = tf + 1;
+     after every other block has been published (it has consumed them all).
+     Hand-off of x: every entry is published as two 8-byte words {epoch | low half}, {epoch | high half}
+     (aligned 8-byte accesses are single-copy atomic), so a consumer that polls the entry itself needs ONE
+     memory round trip per dependent step instead of flag-then-data, and a word can never be mistaken for
+     one of an earlier sweep. */
   const unsigned want = __hip_atomic_load(tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const size_t npad = (size_t)nblk * TS;
   __shared__ double sx[2][TRSV_MAXR][TS];
   __shared__ double sW[TS][TS + 1];
   __shared__ double srhs[TRSV_MAXR][TS];
@@ -966,8 +970,19 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
       const int buf = sstep & 1;
       for (int e = tid; e < nrhs * TS; e += 256) {        /* nrhs can be 5: more entries than threads */
         const int r = e / TS, c = e % TS;
-        while (__hip_atomic_load(flags + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
-        sx[buf][r][c] = (j0 + c < n) ? __hip_atomic_load(xout + r * ldb + j0 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        double v = 0.0;
+        if (j0 + c < n) {
+          const unsigned long long *q = xq + 2 * ((size_t)r * npad + j0 + c);
+          unsigned long long w0, w1;
+          for (;;) {
+            w0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w0 >> 32) == want && (unsigned)(w1 >> 32) == want) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          v = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+        }
+        sx[buf][r][c] = v;
       }
       __syncthreads();
       if (mode == 1) {
@@ -1039,13 +1054,18 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
           p2 = fma(sW[c + 2][lane], srhs[r][c + 2], p2); p3 = fma(sW[c + 3][lane], srhs[r][c + 3], p3);
         }
       }
-      if (lane < nbI) __hip_atomic_store(xout + r * ldb + i0 + lane, (p0 + p1) + (p2 + p3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane < nbI) {
+        const double xv = (p0 + p1) + (p2 + p3);
+        unsigned long long *q = xq + 2 * ((size_t)r * npad + i0 + lane);
+        const unsigned long long tag = (unsigned long long)want << 32;
+        __hip_atomic_store(q, tag | (unsigned)__double2loint(xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, tag | (unsigned)__double2hiint(xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xout[r * ldb + i0 + lane] = xv;
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_store(flags + I, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == nblk - 1) __hip_atomic_store(tf, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* sweep complete */
+    if (t == nblk - 1) {                                 /* sweep complete: every other block was consumed above */
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(tf, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1062,10 +1082,10 @@ static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
     LAUNCH_CHECK(ctx);
   }
   static const bool no_df = getenv("GSL_SINTERP_NO_DATAFLOW_TRSV") && getenv("GSL_SINTERP_NO_DATAFLOW_TRSV")[0] == '1';
-  if (use_inv && !no_df && ctx->sk_wgs > 0 && ctx->d_tf && ctx->tf_count >= nblk + 1) {
+  if (use_inv && !no_df && ctx->sk_wgs > 0 && ctx->d_tf && ctx->tf_count >= nblk + 1 && ctx->d_xq) {
     const unsigned G = (unsigned)(nblk < (size_t)ctx->sk_wgs ? nblk : (size_t)ctx->sk_wgs);
     hipLaunchKernelGGL(trsv_dataflow_kernel, dim3(G), dim3(256), 0, ctx->stream, T, ldt, n, (const double *)b, xout, ldb, nrhs, mode,
-                       (const double *)d_inv, ctx->d_tf, (unsigned)nblk);
+                       (const double *)d_inv, ctx->d_tf, ctx->d_xq, (unsigned)nblk);
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }
@@ -1112,6 +1132,10 @@ static int trsv_multi_ex(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
       const size_t cnt = need < 1024 ? 1024 : need * 2;
       HIP_OK(ctx, hipMalloc((void **)&ctx->d_tf, cnt * sizeof(unsigned)));
       HIP_OK(ctx, hipMemset(ctx->d_tf, 0, cnt * sizeof(unsigned)));
+      if (ctx->d_xq) { HIP_OK(ctx, hipFree(ctx->d_xq)); ctx->d_xq = NULL; }
+      const size_t xq_bytes = (size_t)TRSV_MAXR * cnt * TS * 2 * sizeof(unsigned long long);   /* epoch 0 everywhere */
+      HIP_OK(ctx, hipMalloc((void **)&ctx->d_xq, xq_bytes));
+      HIP_OK(ctx, hipMemset(ctx->d_xq, 0, xq_bytes));
       HIP_OK(ctx, hipDeviceSynchronize());
       ctx->tf_count = cnt;
       for (int i = 2; i < 4; i++)                       /* cached sweep graphs hold the old pointer */

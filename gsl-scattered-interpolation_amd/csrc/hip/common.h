@@ -50,6 +50,7 @@ struct gsl_sinterp_hip_ctx {
      publishes with epoch + 1 and its last block advances the epoch. */
   unsigned *d_tf;
   size_t tf_count;
+  unsigned long long *d_xq; /* hand-off buffer of the sweeps: per entry {epoch|lo32}, {epoch|hi32} */
   char err[512];
 };
 
