@@ -157,11 +157,92 @@ __device__ __forceinline__ NodeRec load_rec(const NodeRec *__restrict__ rec, int
   return r;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Jump table (index-exact grid locator).  The walk from the root spends its first
+   levels in simplices that contain whole neighbourhoods of targets.  For every cell of a G x G grid
+   over the targets' bounding box this kernel follows the walk for the CELL: it descends from the
+   root while, in the reference's child order, every earlier valid child provably rejects every point
+   of the (slightly enlarged) cell -- some barycentric coordinate <= -JUMP_DELTA at all four corners,
+   hence (affine) everywhere in the cell -- and the next one provably accepts it (all coordinates in
+   [JUMP_DELTA, 1 - JUMP_DELTA] at the corners).  By induction the reference walk of ANY target in the
+   cell passes through the recorded node with the same persistent coordinates, so starting there
+   changes no result.  JUMP_DELTA = 1e-7 is eight orders above the rounding of a well-conditioned 2x2 solve (and the cage, whose barycentric coordinates over the data are ~1e-4, still classifies). */
+#define JUMP_DELTA 1e-7
+#define JUMP_SLACK 1e-6
+
+__device__ __forceinline__ double key_to_double(unsigned long long k)   /* inverse of sort.hip's dkey */
+{
+  unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+/* +1: the enlarged cell is provably inside the node's simplex, -1: provably outside, 0: undecided */
+__device__ __forceinline__ int classify_cell(const NodeRec &r, const double (&cx)[2], const double (&cy)[2], double s0, double s1)
+{
+  bool in = true;
+  double mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      double c0, c1;
+      solve_node(r, cx[a], cy[b], s0, s1, c0, c1);
+      const double c2 = 1.0 - c0 - c1;
+      in = in && (c0 >= JUMP_DELTA) && (c1 >= JUMP_DELTA) && (c2 >= JUMP_DELTA);     /* NaN -> false */
+      mx[0] = fmax(mx[0], c0 == c0 ? c0 : INFINITY);
+      mx[1] = fmax(mx[1], c1 == c1 ? c1 : INFINITY);
+      mx[2] = fmax(mx[2], c2 == c2 ? c2 : INFINITY);
+    }
+  if (in) return 1;
+  if (mx[0] <= -JUMP_DELTA || mx[1] <= -JUMP_DELTA || mx[2] <= -JUMP_DELTA) return -1;
+  return 0;
+}
+
+__global__ void __launch_bounds__(256)
+jump_build_kernel(int n_nodes, const NodeRec *__restrict__ rec, double s0, double s1, const unsigned long long *__restrict__ box,
+                  int G, int *__restrict__ jump)
+{
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= G * G) return;
+  const int ix = cell % G, iy = cell / G;
+  const double lo0 = key_to_double(box[0]), hi0 = key_to_double(box[1]), lo1 = key_to_double(box[2]), hi1 = key_to_double(box[3]);
+  const double w0 = (hi0 - lo0) / G, w1 = (hi1 - lo1) / G;
+  const double cx[2] = {lo0 + w0 * ix - JUMP_SLACK * w0, lo0 + w0 * (ix + 1) + JUMP_SLACK * w0};
+  const double cy[2] = {lo1 + w1 * iy - JUMP_SLACK * w1, lo1 + w1 * (iy + 1) + JUMP_SLACK * w1};
+  int node = 0;
+  NodeRec cur = load_rec(rec, 0);
+  if (!(w0 >= 0.0 && w1 >= 0.0) || META_SINGULAR(cur.meta) || classify_cell(cur, cx, cy, s0, s1) != 1) { jump[cell] = 0; return; }
+  for (int guard = 0; guard < 4096 && META_TYPE(cur.meta) != 0; guard++) {
+    const int nc = META_NCHILD(cur.meta);
+    int next = -1;
+    NodeRec nrec = cur;
+    for (int i = 0; i < nc; i++) {
+      const int ch = i == 0 ? cur.child[0] : (i == 1 ? cur.child[1] : cur.child[2]);
+      if (!(ch > 0 && ch < n_nodes)) continue;          /* the reference does not test these */
+      const NodeRec cr = load_rec(rec, ch);
+      if (META_SINGULAR(cr.meta)) continue;             /* tested without a solve: never a hit */
+      const int cls = classify_cell(cr, cx, cy, s0, s1);
+      if (cls == 1) { next = ch; nrec = cr; }
+      if (cls != -1) break;                             /* accepted, or undecided: stop looking */
+    }
+    if (next < 0) break;
+    node = next;
+    cur = nrec;
+  }
+  jump[cell] = node;
+}
+
 __global__ void __launch_bounds__(256)
 bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, double s0, double s1,
                  const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
-                 int *__restrict__ leaf_out, unsigned long long *__restrict__ n_outside, const int *__restrict__ perm)
+                 int *__restrict__ leaf_out, unsigned long long *__restrict__ n_outside, const int *__restrict__ perm,
+                 const int *__restrict__ jump, int G, const unsigned long long *__restrict__ box)
 {
+  double jlo0 = 0, jlo1 = 0, jw0 = 0, jw1 = 0;
+  if (jump) {
+    jlo0 = key_to_double(box[0]); jlo1 = key_to_double(box[2]);
+    jw0 = (key_to_double(box[1]) - jlo0) / G; jw1 = (key_to_double(box[3]) - jlo1) / G;
+  }
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x; slot < m; slot += stride) {
     /* cell-sorted order: the 64 lanes of a wave hold spatial neighbours and descend through
@@ -170,16 +251,36 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
     const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
     /* coords persist across tests exactly like accel->coords in the reference */
     double c0 = 0, c1 = 0;
-    NodeRec cur = load_rec(rec, 0);
-    bool in_cage = false;
-    if (!META_SINGULAR(cur.meta)) { solve_node(cur, y0, y1, s0, s1, c0, c1); in_cage = inside_unit(c0, c1); }
-    if (!in_cage) {                                     /* linear_simplex.c:341-347 (q7: no abort) */
-      values[k] = __builtin_nan("");
-      if (leaf_out) leaf_out[k] = -1;
-      atomicAdd(n_outside, 1ULL);
-      continue;
-    }
     int node = 0;
+    NodeRec cur;
+    bool started = false;
+    if (jump && jw0 > 0.0 && jw1 > 0.0 && y0 == y0 && y1 == y1) {
+      /* the node the reference walk of every target of this grid cell passes through (jump_build_kernel);
+         the target must lie in the enlarged cell that was classified */
+      int ix = (int)((y0 - jlo0) / jw0), iy = (int)((y1 - jlo1) / jw1);
+      ix = ix < 0 ? 0 : (ix >= G ? G - 1 : ix);
+      iy = iy < 0 ? 0 : (iy >= G ? G - 1 : iy);
+      const bool in_cell = y0 >= jlo0 + jw0 * ix - JUMP_SLACK * jw0 && y0 <= jlo0 + jw0 * (ix + 1) + JUMP_SLACK * jw0 &&
+                           y1 >= jlo1 + jw1 * iy - JUMP_SLACK * jw1 && y1 <= jlo1 + jw1 * (iy + 1) + JUMP_SLACK * jw1;
+      const int start = in_cell ? jump[iy * G + ix] : 0;
+      if (start > 0 && start < n_nodes) {
+        cur = load_rec(rec, start);
+        solve_node(cur, y0, y1, s0, s1, c0, c1);        /* the reference's persistent coordinates at this node */
+        if (inside_unit(c0, c1)) { node = start; started = true; }
+      }
+    }
+    if (!started) {
+      c0 = 0; c1 = 0;
+      cur = load_rec(rec, 0);
+      bool in_cage = false;
+      if (!META_SINGULAR(cur.meta)) { solve_node(cur, y0, y1, s0, s1, c0, c1); in_cage = inside_unit(c0, c1); }
+      if (!in_cage) {                                   /* linear_simplex.c:341-347 (q7: no abort) */
+        values[k] = __builtin_nan("");
+        if (leaf_out) leaf_out[k] = -1;
+        atomicAdd(n_outside, 1ULL);
+        continue;
+      }
+    }
     int guard = 0;
     while (META_TYPE(cur.meta) != 0 && guard++ < 4096) { /* depth is O(log N); bound the walk */
       const int nc = META_NCHILD(cur.meta);
@@ -249,6 +350,28 @@ extern "C" int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   hipLaunchKernelGGL(tree_pack_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, n_nodes, d_type, d_pidx,
                      d_links, n_points, d_points, g, (NodeRec *)d_records);
   LAUNCH_CHECK(ctx);
+  /* jump table over the bounding box of the data (see jump_build_kernel): a property of the packed DAG,
+     built once here; evaluations of these records on this context start their walks from it */
+  ctx->jump_rec = NULL;
+  static const bool no_jump = getenv("GSL_SINTERP_NO_JUMP") && getenv("GSL_SINTERP_NO_JUMP")[0] == '1';
+  if (!no_jump && n_nodes >= 2048 && n_points >= 3 && d_points) {
+    int G = 32;
+    while (G < 1024 && (double)G * G < 2.5 * (double)n_nodes) G *= 2;
+    const size_t bytes = 64 + (size_t)G * G * sizeof(int);
+    if (bytes > ctx->jumpt_bytes) {
+      if (ctx->d_jumpt) { HIP_OK(ctx, hipStreamSynchronize(ctx->stream)); HIP_OK(ctx, hipFree(ctx->d_jumpt)); ctx->d_jumpt = NULL; ctx->jumpt_bytes = 0; }
+      HIP_OK(ctx, hipMalloc(&ctx->d_jumpt, bytes));
+      ctx->jumpt_bytes = bytes;
+    }
+    unsigned long long *d_box = (unsigned long long *)ctx->d_jumpt;
+    int st = sinterp_bbox_keys(ctx, d_points, (size_t)n_points, 2, 2, d_box);
+    if (st) return st;
+    hipLaunchKernelGGL(jump_build_kernel, dim3((unsigned)(((size_t)G * G + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes,
+                       (const NodeRec *)d_records, g.scale[0], g.scale[1], (const unsigned long long *)d_box, G,
+                       (int *)((char *)ctx->d_jumpt + 64));
+    LAUNCH_CHECK(ctx);
+    ctx->jump_rec = d_records; ctx->jump_nodes = n_nodes; ctx->jump_G = G;
+  }
   return ST_SUCCESS;
 }
 
@@ -277,17 +400,49 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   if (m == 0) return ST_SUCCESS;
   unsigned long long *d_count = (unsigned long long *)ctx->d_scratch;
   HIP_OK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
-  int *d_perm = NULL;
+  /* m >= 4096: the targets are gathered into grid-cell order, swept contiguously, and the results
+     un-sorted afterwards (see sinterp_sort_reorder) */
+  sinterp_sorted srt;
+  bool sorted = false;
   if (m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1')) {
-    int st = sinterp_sort_targets(ctx, d_targets, m, ttda, 2, 64, &d_perm);
+    int st = sinterp_sort_reorder(ctx, d_targets, m, ttda, 2, 64, &srt);
     if (st) return st;
+    sorted = true;
+  }
+  int *d_jump = NULL;
+  int G = 0;
+  const unsigned long long *d_jbox = NULL;
+  static const bool no_jump = getenv("GSL_SINTERP_NO_JUMP") && getenv("GSL_SINTERP_NO_JUMP")[0] == '1';
+  if (!no_jump && ctx->jump_rec == d_records && ctx->jump_nodes == n_nodes && ctx->d_jumpt) {
+    /* the table tree_pack built for these records on this context */
+    d_jump = (int *)((char *)ctx->d_jumpt + 64);
+    d_jbox = (const unsigned long long *)ctx->d_jumpt;
+    G = ctx->jump_G;
+  } else if (sorted && !no_jump && n_nodes >= 2048) {
+    /* records packed elsewhere (e.g. received by broadcast): a table over THIS batch's bounding box */
+    /* grid fine enough that a cell is about the size of the final triangles (~n_nodes/9 points) */
+    G = 32;
+    while (G < 1024 && (double)(2 * G) * (2 * G) <= (double)n_nodes) G *= 2;
+    void *jb = NULL;
+    int st = sinterp_sortbuf2(ctx, (size_t)G * G * sizeof(int), &jb);
+    if (st) return st;
+    d_jump = (int *)jb;
+    hipLaunchKernelGGL(jump_build_kernel, dim3((unsigned)((G * G + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes,
+                       (const NodeRec *)d_records, h_scale[0], h_scale[1], (const unsigned long long *)srt.box, G, d_jump);
+    d_jbox = srt.box;
   }
   size_t blocks = (m + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(bary_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
-                     (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], d_targets, m, ttda,
-                     d_values, d_leaf, d_count, (const int *)d_perm);
+                     (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1],
+                     sorted ? (const double *)srt.ys : d_targets, m, sorted ? (size_t)2 : ttda, sorted ? srt.vs : d_values,
+                     sorted ? (d_leaf ? srt.ls : (int *)NULL) : d_leaf, d_count, (const int *)NULL, (const int *)d_jump, G,
+                     d_jbox);
   LAUNCH_CHECK(ctx);
+  if (sorted) {
+    int st = sinterp_unsort(ctx, &srt, m, d_values, d_leaf);
+    if (st) return st;
+  }
   if (h_n_outside) {
     unsigned long long cnt = 0;
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));

@@ -51,6 +51,12 @@ struct gsl_sinterp_hip_ctx {
   unsigned *d_tf;
   size_t tf_count;
   unsigned long long *d_xq; /* hand-off buffer of the sweeps: per entry {epoch|lo32}, {epoch|hi32} */
+  /* jump table of the barycentric walk built by tree_pack over the data's bounding box (bary.hip):
+     [64 B box keys][G*G node indices]; valid for records == jump_rec with jump_nodes nodes */
+  void *d_jumpt;
+  size_t jumpt_bytes;
+  const void *jump_rec;
+  int jump_nodes, jump_G;
   char err[512];
 };
 
@@ -120,11 +126,28 @@ int sinterp_sortbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 /* sort.hip: permutation that groups the targets by cell of a uniform grid (~per_cell each) */
 int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
                          int **d_perm_out);
+/* The same sort, but the targets are physically gathered into cell order (dense [m][dim]) and the
+   results come back through sinterp_unsort: the sweep kernels then read and write contiguously, the
+   only scattered accesses are one 8*dim-byte write per target here and one 8(+4)-byte READ per target in
+   the un-sort (a permutation-indirect kernel pays a scattered read AND partial-sector scattered writes). */
+struct sinterp_sorted {
+  double *ys;                   /* [m][dim] targets in cell order */
+  double *vs;                   /* [m] values in cell order (filled by the sweep) */
+  int *ls;                      /* [m] leaf indices in cell order (barycentric sweep) */
+  unsigned *cellid, *slot, *offset;
+  unsigned long long *box;      /* bounding-box keys, box[2c] = min, box[2c+1] = max */
+};
+int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
+                         sinterp_sorted *out);
+int sinterp_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf);
+
 /* the centres: cells visited in Morton order (consecutive runs are spatially compact), original
    index order inside a cell (deterministic summation order); uses its own buffer */
 int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, size_t xtda, int dim, int per_cell,
                          int **d_perm_out);
 int sinterp_sortbuf2(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
+/* sort.hip: bounding box of n points as order-preserving keys, box[2c] = min, box[2c+1] = max (device, 48 bytes) */
+int sinterp_bbox_keys(gsl_sinterp_hip_ctx *ctx, const double *d_p, size_t n, size_t tda, int dim, unsigned long long *d_box);
 int sinterp_centbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 
 #endif

@@ -82,6 +82,7 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_sk_flags) (void)hipFree(ctx->d_sk_flags);
   if (ctx->d_tf) (void)hipFree(ctx->d_tf);
   if (ctx->d_xq) (void)hipFree(ctx->d_xq);
+  if (ctx->d_jumpt) (void)hipFree(ctx->d_jumpt);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -231,3 +231,93 @@ int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, 
   *d_perm_out = perm;
   return ST_SUCCESS;
 }
+
+/* ---- physical reorder ---------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+cell_scatter_points_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, const unsigned *__restrict__ cellid,
+                           const unsigned *__restrict__ slot, const unsigned *__restrict__ offset, double *__restrict__ ys)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    const size_t pos = (size_t)offset[cellid[k]] + slot[k];
+    if (dim == 2) {
+      double2 v = make_double2(y[k * ytda], y[k * ytda + 1]);
+      *reinterpret_cast<double2 *>(ys + pos * 2) = v;               /* one 16-byte store */
+    } else {
+      for (int c = 0; c < dim; c++) ys[pos * dim + c] = y[k * ytda + c];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+unsort_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ slot, const unsigned *__restrict__ offset, size_t m,
+              const double *__restrict__ vs, double *__restrict__ values, const int *__restrict__ ls, int *__restrict__ leaf)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    const size_t pos = (size_t)offset[cellid[k]] + slot[k];
+    if (values) values[k] = vs[pos];
+    if (leaf) leaf[k] = ls[pos];
+  }
+}
+
+int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
+                         sinterp_sorted *out)
+{
+  memset(out, 0, sizeof *out);
+  if (m == 0) return ST_SUCCESS;
+  if (m > 0x7fffffffULL) return sinterp_fail(ctx, ST_EINVAL, "sort_reorder: more than 2^31 targets", hipSuccess, __FILE__, __LINE__);
+  double cells = (double)m / (double)(per_cell > 0 ? per_cell : 64);
+  int g = (int)ceil(pow(cells < 1 ? 1.0 : cells, 1.0 / dim));
+  const int gmax = dim == 1 ? (1 << 20) : (dim == 2 ? 1024 : 100);
+  g = g < 1 ? 1 : (g > gmax ? gmax : g);
+  size_t ncell = 1;
+  for (int c = 0; c < dim; c++) ncell *= (size_t)g;
+  /* layout: box | ys | vs | ls | cellid | slot | count(+1) ; every section 16-byte aligned */
+  auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const size_t o_ys = 64, o_vs = o_ys + up(m * dim * 8), o_ls = o_vs + up(m * 8), o_cell = o_ls + up(m * 4),
+               o_slot = o_cell + up(m * 4), o_cnt = o_slot + up(m * 4), bytes = o_cnt + up((ncell + 1) * 4);
+  void *buf = NULL;
+  int st = sinterp_sortbuf(ctx, bytes, &buf);
+  if (st) return st;
+  char *b = (char *)buf;
+  out->box = (unsigned long long *)b;
+  out->ys = (double *)(b + o_ys); out->vs = (double *)(b + o_vs); out->ls = (int *)(b + o_ls);
+  out->cellid = (unsigned *)(b + o_cell); out->slot = (unsigned *)(b + o_slot); out->offset = (unsigned *)(b + o_cnt);
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, out->box);
+  HIP_OK(ctx, hipMemsetAsync(out->offset, 0, ncell * 4, ctx->stream));
+  size_t blocks = (m + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, out->box);
+  hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g,
+                     (const unsigned long long *)out->box, out->cellid, out->slot, out->offset);
+  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, out->offset, (unsigned)ncell);
+  hipLaunchKernelGGL(cell_scatter_points_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim,
+                     (const unsigned *)out->cellid, (const unsigned *)out->slot, (const unsigned *)out->offset, out->ys);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+int sinterp_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf)
+{
+  if (m == 0 || (!d_values && !d_leaf)) return ST_SUCCESS;
+  size_t blocks = (m + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unsort_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->cellid,
+                     (const unsigned *)s->slot, (const unsigned *)s->offset, m, (const double *)s->vs, d_values,
+                     (const int *)s->ls, d_leaf);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+int sinterp_bbox_keys(gsl_sinterp_hip_ctx *ctx, const double *d_p, size_t n, size_t tda, int dim, unsigned long long *d_box)
+{
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_box);
+  if (n) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_p, n, tda, dim, d_box);
+  }
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}

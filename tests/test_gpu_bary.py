@@ -166,3 +166,58 @@ def test_facade_linear_simplex(pkg, orc):
     assert st == 0 and np.float64(v).view(np.uint64) == bits(ovals[7:8])[0]
     st, v = s.eval_e([1e12, 0.0])
     assert st == pkg.capi.GSL_EDOM and np.isnan(v)       # like gsl_interp_eval_e outside [xmin, xmax]
+
+
+@pytest.mark.parametrize("packer_is_evaluator", [True, False])
+def test_jump_table_is_exact_on_adversarial_targets(pkg, orc, packer_is_evaluator):
+    """The walk starts from a per-grid-cell node (jump table, bary.hip) instead of the root.  Targets that
+    stress exactly that: on the data points, on midpoints of point pairs, ON the lines of the jump grid
+    (computed with the kernel's own expressions), just outside the data's bounding box, plus a random
+    cloud -- leaf indices and values must stay bit-identical to the oracle's walk from the root.  Both table
+    flavours: built by tree_pack over the data's box (packer == evaluator) and built per batch over the
+    targets' box (records packed on another context, the multi-GPU broadcast situation)."""
+    import torch
+    n = 20000
+    x = orc.synth_centres(n, 2) * np.array([2.0, 0.7]) + np.array([5.0, -3.0])
+    f = orc.synth_response(x)
+    t, o = build_pair(pkg, orc, x)
+    nn = t.n_nodes
+    G = 32
+    while G < 1024 and G * G < 2.5 * nn:
+        G *= 2
+    lo, hi = x.min(axis=0), x.max(axis=0)
+    w = (hi - lo) / G
+    rng = np.random.default_rng(11)
+    lines = []
+    for i in range(G + 1):
+        lines.append(np.column_stack([np.full(8, lo[0] + w[0] * i), lo[1] + (hi[1] - lo[1]) * rng.random(8)]))
+        lines.append(np.column_stack([lo[0] + (hi[0] - lo[0]) * rng.random(8), np.full(8, lo[1] + w[1] * i)]))
+    corners = np.array([[lo[0] + w[0] * i, lo[1] + w[1] * j] for i in range(0, G + 1, 7) for j in range(0, G + 1, 5)])
+    outside_box = np.column_stack([hi[0] + 0.01 * (1 + rng.random(50)), lo[1] + (hi[1] - lo[1]) * rng.random(50)])
+    pairs = rng.integers(0, n, size=(20000, 2))
+    y = np.concatenate([x, 0.5 * (x[pairs[:, 0]] + x[pairs[:, 1]]), np.concatenate(lines), corners, outside_box,
+                        orc.synth_targets(3, 30000, 2) * np.array([2.0, 0.7]) + np.array([5.0, -3.0])])
+    m = len(y)
+    types, pidx, links = t.arrays()
+    sh = t.shuffle()
+    ctx_pack = pkg.HipContext.on_torch_stream(0)
+    ctx_eval = ctx_pack if packer_is_evaluator else pkg.HipContext.on_torch_stream(0)
+    d_type, d_pidx, d_links = dev(types), dev(pidx), dev(links)
+    d_pts, d_resp = dev(x[sh]), dev(f[sh])
+    rec = torch.empty(nn * 64, dtype=torch.uint8, device="cuda")
+    tab = torch.empty(nn * 32, dtype=torch.uint8, device="cuda")
+    geom = t.geom()
+    ctx_pack.tree_pack(nn, ptr(d_type), ptr(d_pidx), ptr(d_links), n, ptr(d_pts), geom, ptr(rec))
+    ctx_pack.tree_bind(nn, ptr(d_pidx), n, ptr(d_resp), ptr(tab))
+    ctx_pack.sync()
+    d_y = dev(y)
+    d_v = torch.empty(m, dtype=torch.float64, device="cuda")
+    d_l = torch.empty(m, dtype=torch.int32, device="cuda")
+    outside = ctx_eval.bary_eval(nn, ptr(rec), ptr(tab), geom[8:10], ptr(d_y), m, 2, ptr(d_v), ptr(d_l), count_outside=True)
+    ovals, oleaf = o.eval_many(x, f, y)
+    assert outside == 0
+    assert np.array_equal(d_l.cpu().numpy(), oleaf)
+    assert np.array_equal(bits(d_v.cpu().numpy()), bits(ovals))
+    # a small batch takes the unsorted path (and, on the packing context, still the table)
+    outside = ctx_eval.bary_eval(nn, ptr(rec), ptr(tab), geom[8:10], ptr(d_y), 3000, 2, ptr(d_v), ptr(d_l), count_outside=True)
+    assert np.array_equal(d_l.cpu().numpy()[:3000], oleaf[:3000]) and np.array_equal(bits(d_v.cpu().numpy()[:3000]), bits(ovals[:3000]))
