@@ -100,9 +100,9 @@ cell_hist_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, i
   }
 }
 
-/* in-place exclusive scan of count[0..ncell) by one workgroup, 8 consecutive entries per thread and
+/* in-place exclusive scan of count[0..ncell) by one workgroup, 32 consecutive entries per thread and
    pass; count[ncell] receives the total */
-#define SCAN_PER 8
+#define SCAN_PER 32
 __global__ void __launch_bounds__(1024)
 cell_scan_kernel(unsigned *__restrict__ count, unsigned ncell)
 {
