@@ -186,6 +186,10 @@ cell_order_kernel(const unsigned *__restrict__ offset, unsigned ncell, int *__re
   const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncell) return;
   const unsigned b = offset[c], e = offset[c + 1];
+  /* one thread per cell: cells hold ~8 centres.  A degenerate cloud (thousands of centres in one cell)
+     would turn this insertion sort into seconds of single-thread work; such a cell keeps the order of
+     the atomic scatter (the sum is then reproducible to rounding only) */
+  if (e - b > 2048u) return;
   for (unsigned i = b + 1; i < e; i++) {
     const int v = perm[i];
     unsigned j = i;
