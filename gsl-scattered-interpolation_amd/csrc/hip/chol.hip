@@ -193,33 +193,42 @@ extern "C" int gsl_sinterp_hip_debug_diag_ts(unsigned long long *out) { return (
    J+1's entries k < J -- final before column J starts -- come back as uniform-address ds_read_b128
    (two entries per instruction), issued before column J's rsq chain and consumed in its latency
    shadow (a wave issues in order: the FMAs are interleaved by hand between the ~8 dependent chain
-   ops, sched_barrier pins the order; measured dependent-issue latency of v_fma_f64 is ~16 cycles).  Only the k = J term needs a readlane. */
+   ops, sched_barrier pins the order).  Only the k = J term needs a readlane. */
 template <int J, int SLOT>
-__device__ __forceinline__ void potrf32_fill(const double (&a)[CB], const double (&r)[CB], double (&p)[4])
+__device__ __forceinline__ void potrf32_fill(const double (&a)[CB], const double (&rp)[CB], double rlast, double (&p)[4])
 {
-  /* four accumulators: a dependent fp64 FMA issues every ~16 cycles, an independent one every 4 */
-  if constexpr (J + 1 < CB && SLOT >= 2) {
+  /* partial dot product of column J+1: terms k < J-1 use row entries fetched one column ago (rp), the
+     term k = J-1 the entry fetched at the start of this column (rlast), consumed last; four accumulators */
+  if constexpr (J + 1 < CB && SLOT >= 2 && SLOT <= 6 && J >= 2) {
 #pragma unroll
-    for (int k = ((SLOT - 2) * J) / 6; k < ((SLOT - 1) * J) / 6; k++) p[k & 3] = fma(-a[k], r[k], p[k & 3]);
+    for (int k = ((SLOT - 2) * (J - 1)) / 5; k < ((SLOT - 1) * (J - 1)) / 5; k++) p[k & 3] = fma(-a[k], rp[k], p[k & 3]);
   }
+  if constexpr (J + 1 < CB && SLOT == 7 && J >= 1) p[(J - 1) & 3] = fma(-a[J - 1], rlast, p[(J - 1) & 3]);
   __builtin_amdgcn_sched_barrier(0);
 }
 
+/* rp: entries k < J-1 of row J+1 of L, fetched from the LDS image during column J-1 */
 template <int J>
-__device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double cur, int &badcol, const double *D, double *colp, int cstride)
+__device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double cur, int &badcol, const double *D, double *colp,
+                                             int cstride, const double (&rp)[CB])
 {
   if constexpr (J < CB) {
     TSTAMP(32 + J);
     double v = cur;
     if constexpr (J > 0) v = fma(-a[J - 1], lane_bcast(a[J - 1], J), v);
     double d = lane_bcast(v, J);
-    double r[CB];
-    if constexpr (J + 1 < CB) {
+    /* LDS reads issued now: the one entry of row J+1 that column J-1 just produced (used in the last
+       fill slot of this column), and row J+2's entries k < J for the NEXT column -- a full column
+       (~200 cycles) ahead of their use, so the ~70-cycle LDS latency never stalls the in-order wave */
+    double rlast = 0.0;
+    if constexpr (J >= 1 && J + 1 < CB) rlast = D[(J + 1) * PQ + (J - 1)];
+    double rn[CB];
+    if constexpr (J + 2 < CB) {
 #pragma unroll
       for (int k = 0; k < J; k += 2) {
-        const double2 t = *reinterpret_cast<const double2 *>(D + (J + 1) * PQ + k);
-        r[k] = t.x;
-        if (k + 1 < CB) r[k + 1] = t.y;
+        const double2 t = *reinterpret_cast<const double2 *>(D + (J + 2) * PQ + k);
+        rn[k] = t.x;
+        if (k + 1 < CB) rn[k + 1] = t.y;
       }
     }
     const bool ok = d > 0.0;                            /* cholesky.c:120-123 */
@@ -233,23 +242,23 @@ __device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double c
     double p[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (J + 1 < CB) p[0] = a[J + 1];
     const double y0 = __builtin_amdgcn_rsq(d);
-    potrf32_fill<J, 0>(a, r, p);
+    potrf32_fill<J, 0>(a, rp, rlast, p);
     const double t = d * y0;
-    potrf32_fill<J, 1>(a, r, p);
+    potrf32_fill<J, 1>(a, rp, rlast, p);
     const double rr = fma(-t, y0, 1.0);
-    potrf32_fill<J, 2>(a, r, p);
+    potrf32_fill<J, 2>(a, rp, rlast, p);
     const double s1 = fma(0.375, rr, 0.5), u = y0 * rr;
-    potrf32_fill<J, 3>(a, r, p);
+    potrf32_fill<J, 3>(a, rp, rlast, p);
     const double inv = fma(u, s1, y0);
-    potrf32_fill<J, 4>(a, r, p);
+    potrf32_fill<J, 4>(a, rp, rlast, p);
     const double an = v * inv, sd0 = d * inv;
-    potrf32_fill<J, 5>(a, r, p);
+    potrf32_fill<J, 5>(a, rp, rlast, p);
     const double sd = fma(fma(-sd0, sd0, d), 0.5 * inv, sd0);
-    potrf32_fill<J, 6>(a, r, p);
+    potrf32_fill<J, 6>(a, rp, rlast, p);
     a[J] = (lane == J) ? sd : an;
     colp[J * cstride] = a[J];                           /* column J of L (row reads of later columns) / of L^-1 */
-    potrf32_fill<J, 7>(a, r, p);
-    potrf32_cols<J + 1>(a, lane, (p[0] + p[1]) + (p[2] + p[3]), badcol, D, colp, cstride);
+    potrf32_fill<J, 7>(a, rp, rlast, p);
+    potrf32_cols<J + 1>(a, lane, (p[0] + p[1]) + (p[2] + p[3]), badcol, D, colp, cstride, rn);
   }
 }
 
@@ -298,7 +307,8 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
       double *colp = is_row ? D + lane * PQ : Dv + jb * PBLK + c;   /* entry J of this lane's vector: colp[J * cstride] */
       const int cstride = is_row ? 1 : PQ;
       int badcol = 0;
-      potrf32_cols<0>(a, lane, a[0], badcol, D, colp, cstride);
+      double r0[CB];                                      /* nothing prefetched before column 0 */
+      potrf32_cols<0>(a, lane, a[0], badcol, D, colp, cstride, r0);
       if (is_row) {
 #pragma unroll
         for (int k = 0; k < CB; k++) D[lane * PQ + k] = (k <= lane) ? a[k] : 0.0;
