@@ -193,6 +193,18 @@ __device__ __forceinline__ int classify_cell(const NodeRec &r, const double (&cx
       mx[1] = fmax(mx[1], c1 == c1 ? c1 : INFINITY);
       mx[2] = fmax(mx[2], c2 == c2 ? c2 : INFINITY);
     }
+  /* The argument needs the computed coordinates to be affine in the target up to an error far below
+     JUMP_DELTA.  For a badly conditioned (sliver) node that is not a given: check it -- the coordinates
+     of the cell centre must equal the mean of the corners' to 1e-9, else the node is left undecided. */
+  {
+    double c0, c1, m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) { solve_node(r, cx[a], cy[b], s0, s1, c0, c1); m0 += 0.25 * c0; m1 += 0.25 * c1; }
+    solve_node(r, 0.5 * (cx[0] + cx[1]), 0.5 * (cy[0] + cy[1]), s0, s1, c0, c1);
+    if (!(fabs(c0 - m0) <= 1e-9 && fabs(c1 - m1) <= 1e-9)) return 0;
+  }
   if (in) return 1;
   if (mx[0] <= -JUMP_DELTA || mx[1] <= -JUMP_DELTA || mx[2] <= -JUMP_DELTA) return -1;
   return 0;
