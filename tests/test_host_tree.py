@@ -94,6 +94,26 @@ def test_degenerate_inputs(pkg, orc):
         assert np.array_equal(a, b)
 
 
+def test_exact_lattice_fails_cleanly_and_jittered_lattice_matches_oracle(pkg, orc):
+    """On an exactly regular lattice (collinear + co-circular points everywhere) the reference's recursive
+    flip cascade never settles and overruns the stack (the oracle, a faithful restatement, does too -- it is
+    not called on that input).  The product bounds the recursion and reports GSL_EFAILED.  The same lattice
+    with 1e-7 jitter builds, bit-identical to the oracle."""
+    n1 = 8
+    gx, gy = np.meshgrid(np.arange(n1) / (n1 - 1.0), np.arange(n1) / (n1 - 1.0))
+    lattice = np.ascontiguousarray(np.column_stack([gx.ravel(), gy.ravel()]))
+    t = pkg.SimplexTree(2, len(lattice))
+    assert t.init(lattice, flags=0, rng=pkg.capi.Rng(0)) == pkg.capi.GSL_EFAILED
+    n1 = 24
+    gx, gy = np.meshgrid(np.arange(n1) / (n1 - 1.0), np.arange(n1) / (n1 - 1.0))
+    x = np.ascontiguousarray(np.column_stack([gx.ravel(), gy.ravel()]) + 1e-7 * np.random.default_rng(1).standard_normal((n1 * n1, 2)))
+    t = pkg.SimplexTree(2, len(x))
+    o = orc.Tree(2, len(x))
+    assert t.init(x, flags=0, rng=pkg.capi.Rng(0)) == 0 and o.init(x, flags=0, seed=0) == 0
+    for a, b in zip(t.arrays(), o.arrays()):
+        assert np.array_equal(a, b)
+
+
 def test_outside_cage_reports_edom(pkg):
     x = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
     t = pkg.SimplexTree(2, 4)
