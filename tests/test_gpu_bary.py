@@ -221,3 +221,32 @@ def test_jump_table_is_exact_on_adversarial_targets(pkg, orc, packer_is_evaluato
     # a small batch takes the unsorted path (and, on the packing context, still the table)
     outside = ctx_eval.bary_eval(nn, ptr(rec), ptr(tab), geom[8:10], ptr(d_y), 3000, 2, ptr(d_v), ptr(d_l), count_outside=True)
     assert np.array_equal(d_l.cpu().numpy()[:3000], oleaf[:3000]) and np.array_equal(bits(d_v.cpu().numpy()[:3000]), bits(ovals[:3000]))
+
+
+@pytest.mark.parametrize("cloud", ["jittered_lattice", "clusters_and_near_collinear"])
+def test_sliver_geometry_stays_bitexact(pkg, orc, cloud):
+    """Point sets that produce sliver triangles and badly conditioned 2x2 systems (a lattice with 1e-7
+    jitter; a 1e-3-wide cluster plus 1500 points within 1e-9 of a line): the jump table must leave the
+    nodes it cannot classify alone, and the batched result must stay bit-identical to the oracle."""
+    rng = np.random.default_rng(5)
+    if cloud == "jittered_lattice":
+        n1 = 48
+        gx, gy = np.meshgrid(np.arange(n1) / (n1 - 1.0), np.arange(n1) / (n1 - 1.0))
+        nodes = np.column_stack([gx.ravel(), gy.ravel()])
+        x = np.ascontiguousarray(nodes + 1e-7 * rng.standard_normal(nodes.shape))
+        extra = nodes                                          # the exact lattice nodes as targets
+    else:
+        x = np.ascontiguousarray(np.concatenate([rng.random((2000, 2)) * 1e-3 + 0.5,
+                                                 np.column_stack([np.linspace(0, 1, 1500), 0.3 + 1e-9 * rng.standard_normal(1500)]),
+                                                 rng.random((1500, 2))]))
+        extra = np.column_stack([np.linspace(0, 1, 3000), np.full(3000, 0.3)])   # along the line itself
+    f = orc.synth_response(x)
+    t, o = build_pair(pkg, orc, x)
+    d = t.device_alloc(0)
+    assert d.set_response(f) == 0
+    y = np.ascontiguousarray(np.concatenate([x, extra, rng.random((20000, 2)), 0.5 + 1e-3 * rng.random((5000, 2))]))
+    st, vals, leaf = d.eval_many(y)
+    ovals, oleaf = o.eval_many(x, f, y)
+    assert st == 0
+    assert np.array_equal(leaf, oleaf)
+    assert np.array_equal(bits(vals), bits(ovals))
