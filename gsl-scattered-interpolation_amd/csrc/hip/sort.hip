@@ -133,6 +133,35 @@ cell_scan_kernel(unsigned *__restrict__ count, unsigned ncell)
   if (threadIdx.x == 0) count[ncell] = s_carry;
 }
 
+/* large cell counts: wave-level scans of 1024-entry runs (coalesced, shuffle based), a single-workgroup
+   scan of the run totals, and an add pass */
+__global__ void __launch_bounds__(256)
+cell_scan_runs_kernel(unsigned *__restrict__ count, unsigned ncell, unsigned *__restrict__ runsum)
+{
+  const int lane = threadIdx.x & 63;
+  const unsigned run = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const unsigned base = run * 1024u;
+  unsigned carry = 0;
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const unsigned i = base + it * 64 + lane;
+    const unsigned v = i < ncell ? count[i] : 0u;
+    unsigned incl = v;
+    for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (i < ncell) count[i] = carry + incl - v;
+    carry += __shfl(incl, 63);
+  }
+  if (lane == 0) runsum[run] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+cell_scan_add_kernel(unsigned *__restrict__ count, unsigned ncell, const unsigned *__restrict__ runsum, unsigned nruns)
+{
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i < ncell) count[i] += runsum[i >> 10];
+  if (i == 0) count[ncell] = runsum[nruns];
+}
+
 __global__ void __launch_bounds__(256)
 cell_scatter_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ slot, size_t m,
                     const unsigned *__restrict__ offset, int *__restrict__ perm)
@@ -140,6 +169,21 @@ cell_scatter_kernel(const unsigned *__restrict__ cellid, const unsigned *__restr
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride)
     perm[offset[cellid[k]] + slot[k]] = (int)k;
+}
+
+
+/* exclusive scan of count[0..ncell), total in count[ncell]; runsum needs ncell/1024 + 2 entries */
+static void launch_cell_scan(gsl_sinterp_hip_ctx *ctx, unsigned *count, size_t ncell, unsigned *runsum)
+{
+  if (ncell <= 32768) {
+    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, (unsigned)ncell);
+    return;
+  }
+  const unsigned nruns = (unsigned)((ncell + 1023) / 1024);
+  hipLaunchKernelGGL(cell_scan_runs_kernel, dim3((nruns + 3) / 4), dim3(256), 0, ctx->stream, count, (unsigned)ncell, runsum);
+  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, runsum, nruns);
+  hipLaunchKernelGGL(cell_scan_add_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->stream, count, (unsigned)ncell,
+                     (const unsigned *)runsum, nruns);
 }
 
 /* perm[i] = index of the i-th target in cell order.  Targets per cell ~ `per_cell`. */
@@ -156,7 +200,7 @@ int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   size_t ncell = 1;
   for (int c = 0; c < dim; c++) ncell *= (size_t)g;
   void *buf = NULL;
-  const size_t bytes = 64 + m * 4 /*perm*/ + m * 4 /*cellid*/ + m * 4 /*slot*/ + (ncell + 1) * 4;
+  const size_t bytes = 64 + m * 4 /*perm*/ + m * 4 /*cellid*/ + m * 4 /*slot*/ + (ncell + 1) * 4 + (ncell / 1024 + 8) * 4;
   int st = sinterp_sortbuf(ctx, bytes, &buf);
   if (st) return st;
   unsigned long long *box = (unsigned long long *)buf;
@@ -171,7 +215,7 @@ int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, box);
   hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g,
                      (const unsigned long long *)box, cellid, slot, count);
-  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, (unsigned)ncell);
+  launch_cell_scan(ctx, count, ncell, count + ncell + 1);
   hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid,
                      (const unsigned *)slot, m, (const unsigned *)count, perm);
   LAUNCH_CHECK(ctx);
@@ -211,7 +255,7 @@ int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, 
   size_t ncell = 1;
   for (int c = 0; c < dim; c++) ncell *= (size_t)g;
   void *buf = NULL;
-  const size_t bytes = 64 + n * 4 + n * 4 + n * 4 + (ncell + 1) * 4;
+  const size_t bytes = 64 + n * 4 + n * 4 + n * 4 + (ncell + 1) * 4 + (ncell / 1024 + 8) * 4;
   int st = sinterp_sortbuf2(ctx, bytes, &buf);
   if (st) return st;
   unsigned long long *box = (unsigned long long *)buf;
@@ -226,7 +270,7 @@ int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, 
   hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_x, n, xtda, dim, box);
   hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_x, n, xtda, dim, -g,
                      (const unsigned long long *)box, cellid, slot, count);
-  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, (unsigned)ncell);
+  launch_cell_scan(ctx, count, ncell, count + ncell + 1);
   hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid,
                      (const unsigned *)slot, n, (const unsigned *)count, perm);
   hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned *)count,
@@ -280,7 +324,7 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   /* layout: box | ys | vs | ls | cellid | slot | count(+1) ; every section 16-byte aligned */
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
   const size_t o_ys = 64, o_vs = o_ys + up(m * dim * 8), o_ls = o_vs + up(m * 8), o_cell = o_ls + up(m * 4),
-               o_slot = o_cell + up(m * 4), o_cnt = o_slot + up(m * 4), bytes = o_cnt + up((ncell + 1) * 4);
+               o_slot = o_cell + up(m * 4), o_cnt = o_slot + up(m * 4), bytes = o_cnt + up((ncell + 1) * 4 + (ncell / 1024 + 8) * 4);
   void *buf = NULL;
   int st = sinterp_sortbuf(ctx, bytes, &buf);
   if (st) return st;
@@ -295,7 +339,7 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, out->box);
   hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g,
                      (const unsigned long long *)out->box, out->cellid, out->slot, out->offset);
-  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, out->offset, (unsigned)ncell);
+  launch_cell_scan(ctx, out->offset, ncell, out->offset + ncell + 1);
   hipLaunchKernelGGL(cell_scatter_points_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim,
                      (const unsigned *)out->cellid, (const unsigned *)out->slot, (const unsigned *)out->offset, out->ys);
   LAUNCH_CHECK(ctx);
