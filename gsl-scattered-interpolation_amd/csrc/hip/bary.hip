@@ -368,7 +368,7 @@ extern "C" int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   static const bool no_jump = getenv("GSL_SINTERP_NO_JUMP") && getenv("GSL_SINTERP_NO_JUMP")[0] == '1';
   if (!no_jump && n_nodes >= 2048 && n_points >= 3 && d_points) {
     int G = 32;
-    while (G < 1024 && (double)G * G < 2.5 * (double)n_nodes) G *= 2;
+    while (G < 4096 && (double)G * G < 40.0 * (double)n_nodes) G *= 2;
     const size_t bytes = 64 + (size_t)G * G * sizeof(int);
     if (bytes > ctx->jumpt_bytes) {
       if (ctx->d_jumpt) { HIP_OK(ctx, hipStreamSynchronize(ctx->stream)); HIP_OK(ctx, hipFree(ctx->d_jumpt)); ctx->d_jumpt = NULL; ctx->jumpt_bytes = 0; }

@@ -183,7 +183,7 @@ def test_jump_table_is_exact_on_adversarial_targets(pkg, orc, packer_is_evaluato
     t, o = build_pair(pkg, orc, x)
     nn = t.n_nodes
     G = 32
-    while G < 1024 and G * G < 2.5 * nn:
+    while G < 4096 and G * G < 40.0 * nn:               # the rule of gsl_sinterp_hip_tree_pack
         G *= 2
     lo, hi = x.min(axis=0), x.max(axis=0)
     w = (hi - lo) / G
