@@ -224,6 +224,12 @@ def main():
         if os.path.exists(pmc_path):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (not live)
             pmc = json.load(open(pmc_path)).get(args.config, {})
         out.update(rooflines(cfg, n, dim, m_rank, ph_ms, dominant, extra, gemm, pmc))
+        mfma_path = os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")
+        if os.path.exists(mfma_path):     # MFMA-pipe busy fraction of the top GEMM launch from the committed counter pass (not live)
+            mb = json.load(open(mfma_path)).get(args.config, {}).get("gemm_minus_streamk_kernel")
+            for key in ("roofline", "roofline_other"):
+                if mb and out.get(key) and out[key].get("bound") == "mfma":
+                    out[key]["mfma_busy_pmc"] = mb["mfma_busy"]
         out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, n, dim)
