@@ -345,6 +345,8 @@ struct StreamK {
   unsigned steps;               /* K-steps per tile */
   unsigned total;               /* tiles * steps */
   unsigned base, rem;           /* total = G*base + rem: workgroup w starts at w*base + min(w, rem) */
+  unsigned dp_rounds;           /* whole tiles first: round r gives tile r*G + w to workgroup w; the (tile, K-step) space
+                                   of total/steps tiles AFTER those dp_rounds*G tiles is then split as above */
   double *partial;              /* [G][BM*128] */
   unsigned *flags;              /* [G] */
 };
@@ -399,13 +401,19 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
   unsigned it = __builtin_amdgcn_readfirstlane(start_of(gl));
   const unsigned it_end = __builtin_amdgcn_readfirstlane(start_of(gl + 1));
   unsigned tile = __builtin_amdgcn_readfirstlane(it / x.steps);
+  const unsigned dp_tiles = x.dp_rounds * G;
+  unsigned round = 0;
 
-  while (it < it_end) {
-    const unsigned tile_first = tile * x.steps, tile_end = tile_first + x.steps;
-    const unsigned s0 = it - tile_first;
-    const unsigned s1 = it_end < tile_end ? it_end - tile_first : x.steps;
+  /* Whole-tile rounds first: the 32 workgroups of an XCD hold 32 consecutive tiles of the same round and
+     walk K more or less in step, so operand panels are shared in their L2; then the stream-K remainder. */
+  for (;;) {
+    const bool dp = round < x.dp_rounds;
+    if (!dp && it >= it_end) break;
+    const unsigned tile_first = dp ? 0u : tile * x.steps, tile_end = tile_first + x.steps;
+    const unsigned s0 = dp ? 0u : it - tile_first;
+    const unsigned s1 = dp ? x.steps : (it_end < tile_end ? it_end - tile_first : x.steps);
     int tm, tn;
-    decode_tile<BM, BN>(g, tile, tm, tn);
+    decode_tile<BM, BN>(g, dp ? round * G + gl : dp_tiles + tile, tm, tn);
     const size_t row0 = (size_t)tm * BM, col0 = (size_t)tn * BN;
 
     double4_t acc[FM][FN];
@@ -538,8 +546,8 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    it = tile_first + s1;
-    tile++;
+    if (dp) round++;
+    else { it = tile_first + s1; tile++; }
   }
 }
 
@@ -695,11 +703,15 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
         tiles = (unsigned)h.tiles_m * (unsigned)h.tiles_n;
         if (lower_only) { const unsigned tn_ = (unsigned)h.tiles_n; tiles = tn_ * (tn_ + 1) / 2 + ((unsigned)h.tiles_m - tn_) * tn_; }
       }
-      const unsigned long long total64 = (unsigned long long)tiles * x.steps;
+      unsigned long long total64 = (unsigned long long)tiles * x.steps;
       unsigned long long want = total64 / 16;            /* >= 16 K-steps per workgroup ... */
       if (want < tiles) want = tiles;                     /* ... but never fewer workgroups than tiles */
       if (want > (unsigned long long)ctx->sk_wgs) want = (unsigned long long)ctx->sk_wgs;
       const unsigned G = (unsigned)(want ? want : 1);
+      /* many tiles: all but the last full round (and the remainder) as whole tiles */
+      static const bool no_hybrid = getenv("GSL_SINTERP_NO_HYBRID_SK") && getenv("GSL_SINTERP_NO_HYBRID_SK")[0] == '1';
+      x.dp_rounds = (!no_hybrid && tiles / G >= 2) ? tiles / G - 1 : 0;
+      total64 = (unsigned long long)(tiles - x.dp_rounds * G) * x.steps;
       if (total64 < 0x7fffffffull) {
       x.total = (unsigned)total64; x.base = x.total / G; x.rem = x.total % G;
       static bool attr_sk[3] = {false, false, false};
