@@ -19,7 +19,10 @@ TREE_RECORD_BYTES, TREE_LEAFTAB_BYTES = 64, 32
 
 
 def library_path():
-    return os.path.join(_HERE, "libgsl_sinterp.so")
+    """The product library.  GSL_SINTERP_LIBRARY points the bindings at another BUILD of the same
+    sources (the sanitizer build `make asan` of the host C, tests/test_sanitizers.py) -- never at a
+    different implementation: there is no CPU fallback behind this switch."""
+    return os.environ.get("GSL_SINTERP_LIBRARY") or os.path.join(_HERE, "libgsl_sinterp.so")
 
 
 _lib = None

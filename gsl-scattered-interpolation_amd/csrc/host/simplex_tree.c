@@ -467,16 +467,19 @@ static void attach_outer(simplex_tree *tree, const simplex_index *old, simplex_i
    Deliberate difference: the depth is bounded and the build fails with GSL_EFAILED instead of crashing. */
 #define DELAUNAY_MAX_DEPTH 4000
 static __thread int delaunay_depth = 0;
-static __thread int delaunay_runaway = 0;
+static __thread int delaunay_runaway = 0;   /* the current cascade hit the depth bound: unwind without flipping */
+static __thread int delaunay_failed = 0;    /* sticky record of a runaway for simplex_tree_init (reset per insertion) */
 
 static int delaunay_body(simplex_tree *tree, simplex_index leaf, gsl_matrix *data, int face, simplex_tree_accel *accel);
 
 int delaunay(simplex_tree *tree, simplex_index leaf, gsl_matrix *data, int face,
              simplex_tree_accel *accel)
 {
+  if (delaunay_depth == 0) delaunay_runaway = 0;   /* a fresh cascade: do not inherit a failed build's flag */
   if (delaunay_runaway) return 0;
   if (delaunay_depth >= DELAUNAY_MAX_DEPTH) {
     delaunay_runaway = 1;
+    delaunay_failed = 1;
     GSL_ERROR_VAL("delaunay: the flip cascade does not terminate (degenerate point set?)", GSL_EFAILED, 0);
   }
   delaunay_depth++;
@@ -659,10 +662,10 @@ int simplex_tree_init(simplex_tree *tree, gsl_matrix *data, gsl_vector *min, gsl
       simplex_index leaf = -1;
       if (contains2(tree, 0, data, p[0], p[1], tree->accel))
         leaf = descend2(tree, 0, data, p[0], p[1], tree->accel);
-      delaunay_runaway = 0;
+      delaunay_failed = 0;
       ret = leaf < 0 ? GSL_EDOM : insert_point(tree, leaf, data, NULL, tree->accel);
-      if (ret == GSL_SUCCESS && delaunay_runaway) ret = GSL_EFAILED;
-      delaunay_runaway = 0;
+      if (ret == GSL_SUCCESS && delaunay_failed) ret = GSL_EFAILED;
+      delaunay_failed = 0;
       if (ret != GSL_SUCCESS) break;
     }
     gsl_set_error_handler(saved);

@@ -26,6 +26,7 @@
 
 #include "gsl_sinterp_compat.h"
 #include "gsl_sinterp_hip.h"
+#include <assert.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -83,6 +84,29 @@ typedef struct simplex_tree_struct {
 #define SLINK(NODE, I) (SIMP(LINK(NODE, I)))
 #define POINT(NODE, I) (tree->pidx[(I) + SIMP(NODE)->points])
 #define LEAF(NODE) (leaf_type == SIMP(NODE)->type)
+
+/* N_CHILDREN / DATA_POINT / FIND of the reference header (linear_simplex.h:67-102): number of
+   children by node type, the vertex behind a vertex id (cage seed row when negative, data row
+   shuffle[id] otherwise), and the "first index satisfying a predicate" loop. */
+#define N_CHILDREN(NODE) _n_children(tree, NODE)
+#define DATA_POINT(DATA, POINT) _data_point(tree, (DATA), (POINT))
+#define FIND(VAR, PRED, ...)                                                   \
+  for (VAR = 0; VAR < tree->dim + 1; VAR++) {                                  \
+    if (PRED) break;                                                           \
+  }                                                                            \
+  assert(("Couldn't satisfy predicate: ", PRED, "" __VA_ARGS__ "", VAR < tree->dim + 1));
+
+static inline int _n_children(simplex_tree *tree, simplex_index node)
+{
+  const node_type t = SIMP(node)->type;
+  return t == sub_dplus1_type ? tree->dim + 1 : t == sub_d_type ? tree->dim : t == sub_2_type ? 2 : 0;
+}
+
+static inline gsl_vector_view _data_point(simplex_tree *tree, gsl_matrix *data, int point)
+{
+  return point < 0 ? gsl_matrix_row(tree->seed_points, (size_t)(-point - 1))
+                   : gsl_matrix_row(data, gsl_permutation_get(tree->shuffle, (size_t)point));
+}
 
 #define SIMPLEX_TREE_DEFAULT 0
 #define SIMPLEX_TREE_NOSTANDARDIZE (1 << 0)

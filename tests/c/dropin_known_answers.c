@@ -1,7 +1,7 @@
 /*
  * dropin_known_answers.c -- a C program written against include/gsl_sinterp.h the way a user of the
  * reference writes against interpolation/linear_simplex.h: same type names, macros (SIMP / LINK /
- * POINT / LEAF), call sequence and view types.  It checks
+ * POINT / LEAF / N_CHILDREN / DATA_POINT / FIND), call sequence and view types.  It checks
  *   (1) the known answers the reference asserts in interpolation/scattered_interp_example.c:38-77,
  *   (2) the outputs of the reference captured at survey time on its 50-station dataset
  *       (tests/golden/survey_known_answers.json, cfg1: init(data, NULL, NULL, 0, mt19937 seed 0)).
@@ -84,6 +84,29 @@ static void weather_dataset(const char *csv)
     assert(leaf == leaf_expect[k]);
     assert(0 == strcmp(got, value_expect[k]));
   }
+  /* the reference header's N_CHILDREN / DATA_POINT / FIND macros (linear_simplex.h:67-102), used the
+     way linear_simplex.c:365,452,614 uses them: the root was split by the first insertion (d+1
+     children), leaves have none; every neighbour link of a leaf has a reverse link; DATA_POINT
+     resolves cage seeds (negative ids) and data rows through the shuffle. */
+  assert(N_CHILDREN(0) == 3);
+  int n_leaves = 0;
+  for (simplex_index node = 1; node < tree->n_simplexes; node++) {
+    if (!LEAF(node)) { assert(N_CHILDREN(node) == 2 || N_CHILDREN(node) == 3); continue; }
+    n_leaves++;
+    assert(N_CHILDREN(node) == 0);
+    for (int i = 0; i < 3; i++) {
+      simplex_index neighbor = LINK(node, i);
+      if (!neighbor) continue;
+      int j;
+      FIND(j, LINK(neighbor, j) == node, "no reverse link");
+      assert(LEAF(neighbor));
+    }
+  }
+  assert(n_leaves == 2 * 50 + 1);
+  gsl_vector_view seed0 = DATA_POINT(&data.matrix, -1);
+  assert(seed0.vector.data == tree->seed_points->data && seed0.vector.size == 2);
+  gsl_vector_view first = DATA_POINT(&data.matrix, 0);
+  assert(first.vector.data == tab + 3 * gsl_permutation_get(tree->shuffle, 0));
   simplex_tree_free(tree);
   simplex_tree_accel_free(accel);
   gsl_rng_free(rng);

@@ -29,7 +29,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        path = os.environ.get("GSL_SINTERP_ORACLE_LIBRARY") or os.path.join(ORACLE_DIR, "liboracle.so")
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", ORACLE_DIR])
         L = C.CDLL(path, mode=C.RTLD_LOCAL)

@@ -9,8 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_c_program_links_and_reproduces_known_answers(pkg, tmp_path):
     libdir = os.path.dirname(pkg.library_path())
     exe = str(tmp_path / "dropin")
-    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g"] if os.environ.get("GSL_SINTERP_ASAN") else []
+    libname = os.path.basename(pkg.library_path())[3:-3]           # gsl_sinterp, or gsl_sinterp_asan under the sanitizer run
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", *san, "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c", "dropin_known_answers.c"), "-o", exe,
-                           "-L", libdir, "-lgsl_sinterp", "-lm", "-Wl,-rpath," + libdir])
+                           "-L", libdir, "-l" + libname, "-lm", "-Wl,-rpath," + libdir])
     out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "weather_stations.csv")], text=True)
     assert "ok" in out

@@ -1,0 +1,34 @@
+"""CPU-side sanitizer run (the reference has none; its simplex code does manual
+realloc growth and index surgery, linear_simplex.c:23-46).  The host C of the product and the oracle
+are rebuilt under AddressSanitizer + UBSan (`make asan`) and the host-tree, oracle-golden and C drop-in
+tests are re-run against those builds in a child interpreter with the ASan runtime preloaded.
+GPU ASan is not available on the pool; the HIP objects in the sanitizer library are uninstrumented and
+are not called by these tests."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "gsl-scattered-interpolation_amd")
+
+
+def test_host_c_and_oracle_under_asan_ubsan():
+    if os.environ.get("GSL_SINTERP_ASAN"):
+        return                                            # we ARE the child run
+    subprocess.check_call(["make", "-s", "-C", PKG, "asan"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"])
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    env = dict(os.environ,
+               LD_PRELOAD=libasan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",   # the interpreter itself leaks by design
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               GSL_SINTERP_LIBRARY=os.path.join(PKG, "libgsl_sinterp_asan.so"),
+               GSL_SINTERP_ORACLE_LIBRARY=os.path.join(ROOT, "oracle", "liboracle_asan.so"),
+               GSL_SINTERP_ASAN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_host_tree.py"),
+                        os.path.join(ROOT, "tests", "test_oracle_golden.py"),
+                        os.path.join(ROOT, "tests", "test_c_dropin.py")],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    assert "passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
