@@ -152,6 +152,17 @@ rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
   }
 }
 
+/* A target with a NaN coordinate has r^2 = NaN for every centre: the naive sum (oracle) is NaN.  The
+   Gaussian sweeps compare r^2 against the cut-off (false for NaN), so they restore the NaN at the end. */
+template <int DIM>
+__device__ __forceinline__ bool nan_target(const double (&yy)[DIM])
+{
+  bool isn = false;
+#pragma unroll
+  for (int c = 0; c < DIM; c++) isn |= (yy[c] != yy[c]);
+  return isn;
+}
+
 /* ------------------------------------------------------------------------ */
 /* eval sweep: TPT targets per lane, centre tile of TJ entries in LDS          */
 #define EV_THREADS 256
@@ -204,24 +215,29 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
 #pragma unroll
         for (int c = 0; c < DIM; c++) { const double d = yy[t][c] - xc[c]; r2[t] = fma(d, d, r2[t]); }
       }
+      bool take[TPT];
       if (KIND == GSL_SINTERP_RBF_GAUSSIAN) {
-        /* Every distance is computed; the exponential is skipped only when NO lane of the wave
-           has a term above 2^-72 of the kernel's maximum (wave-uniform branch).  Dropped terms
-           are < 2^-72 |w_j| each, i.e. a relative error <= N max|w| 2.1e-22 on O(1) values --
-           ten orders below the 1e-10 parity tolerance (tests/test_gpu_rbf.py). */
+        /* Every distance is computed; a target takes a term only when it is above 2^-72 of the
+           kernel's maximum -- a function of the (target, centre) pair alone, so the value does not
+           depend on which targets share the wave (bit-reproducible whatever the target order).
+           The exponential is skipped when NO lane of the wave takes the term (wave-uniform branch).
+           Dropped terms are < 2^-72 |w_j| each, i.e. a relative error <= N max|w| 2.1e-22 on O(1)
+           values -- ten orders below the 1e-10 parity tolerance (tests/test_gpu_rbf.py). */
         bool need = false;
 #pragma unroll
-        for (int t = 0; t < TPT; t++) need |= (r2[t] * coef > -72.0);
+        for (int t = 0; t < TPT; t++) { take[t] = r2[t] * coef > -72.0; need |= take[t]; }
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
       }
 #pragma unroll
-      for (int t = 0; t < TPT; t++)
-        acc[t] = fma(wj, phi_r2<KIND, LOG_COPIES>(r2[t], KIND == GSL_SINTERP_RBF_TPS ? 1.0 : coef, s_t0, lt_lane), acc[t]);
+      for (int t = 0; t < TPT; t++) {
+        const double a = fma(wj, phi_r2<KIND, LOG_COPIES>(r2[t], KIND == GSL_SINTERP_RBF_TPS ? 1.0 : coef, s_t0, lt_lane), acc[t]);
+        acc[t] = (KIND == GSL_SINTERP_RBF_GAUSSIAN && !take[t]) ? acc[t] : a;
+      }
     }
   }
 #pragma unroll
   for (int t = 0; t < TPT; t++)
-    if (kidx[t] < m) s[kidx[t]] = acc[t];
+    if (kidx[t] < m) s[kidx[t]] = (KIND == GSL_SINTERP_RBF_GAUSSIAN && nan_target<DIM>(yy[t])) ? NAN : acc[t];
 }
 
 /* ------------------------------------------------------------------------ */
@@ -344,23 +360,30 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
         for (int c = 0; c < DIM; c++) xc[c] = s_c[e * (DIM + 1) + c];
         const double wj = s_c[e * (DIM + 1) + DIM];
         double r2[TPT];
-        bool need = false;
+        bool take[TPT], need = false;
 #pragma unroll
         for (int tt = 0; tt < TPT; tt++) {
           r2[tt] = 0.0;
 #pragma unroll
           for (int c = 0; c < DIM; c++) { const double d = yy[tt][c] - xc[c]; r2[tt] = fma(d, d, r2[tt]); }
-          need |= (r2[tt] * coef > -72.0);
+          take[tt] = r2[tt] * coef > -72.0;
+          need |= take[tt];
         }
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+        /* per-target criterion (see rbf_eval_kernel): a culled tile holds only centres every target of
+           the workgroup would reject, so the value is the sum over the centres with term > 2^-72, in
+           Morton order -- independent of the workgroup / wave the target landed in */
 #pragma unroll
-        for (int tt = 0; tt < TPT; tt++) acc[tt] = fma(wj, exp2_tbl(r2[tt] * coef, s_t0), acc[tt]);
+        for (int tt = 0; tt < TPT; tt++) {
+          const double a = fma(wj, exp2_tbl(r2[tt] * coef, s_t0), acc[tt]);
+          acc[tt] = take[tt] ? a : acc[tt];
+        }
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < TPT; t++)
-    if (kidx[t] < m) s[kidx[t]] = acc[t];
+    if (kidx[t] < m) s[kidx[t]] = nan_target<DIM>(yy[t]) ? NAN : acc[t];
 }
 
 template <int TPT>
