@@ -379,7 +379,8 @@ def cpu_baseline(cfg, n, dim, m_total):
     with N^3; the fill and the sweep are timed on a sample and scaled linearly."""
     import concurrent.futures as cf
     import oracle_lib as orc
-    ncores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core share (cpu_count reports the whole host)
+    ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
 
     def par_map(fn, y):
         chunks = np.array_split(np.arange(len(y)), ncores)

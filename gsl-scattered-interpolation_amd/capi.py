@@ -89,7 +89,8 @@ class simplex_tree(C.Structure):
 
 class gsl_sinterp(C.Structure):
     _fields_ = [("type", C.c_void_p), ("dim", C.c_size_t), ("size", C.c_size_t), ("device", C.c_int),
-                ("shape", C.c_double), ("init_flags", C.c_int), ("rng", C.c_void_p), ("state", C.c_void_p)]
+                ("shape", C.c_double), ("init_flags", C.c_int), ("rng", C.c_void_p), ("state", C.c_void_p),
+                ("n_devices", C.c_int), ("devices", C.c_int * 64)]
 
 
 _vp, _i, _sz, _d = C.c_void_p, C.c_int, C.c_size_t, C.c_double
@@ -123,6 +124,20 @@ SIGNATURES = {
     "gsl_sinterp_hip_rbf_solve": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _pi]),
     "gsl_sinterp_hip_gemm_minus": (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _vp, _sz, _i, _vp, _sz, _i]),
     "gsl_sinterp_hip_synth_unit": (_i, [_vp, C.c_uint64, C.c_uint64, _d, _d, _vp, _sz]),
+    # device groups (multi-GPU target shards)
+    "gsl_sinterp_hip_group_create": (_i, [C.POINTER(_vp), _pi, _i]),
+    "gsl_sinterp_hip_group_destroy": (None, [_vp]),
+    "gsl_sinterp_hip_group_size": (_i, [_vp]),
+    "gsl_sinterp_hip_group_device": (_i, [_vp, _i]),
+    "gsl_sinterp_hip_group_ctx": (_vp, [_vp, _i]),
+    "gsl_sinterp_hip_group_transport": (C.c_char_p, [_vp]),
+    "gsl_sinterp_hip_group_last_error": (C.c_char_p, [_vp]),
+    "gsl_sinterp_hip_group_broadcast": (_i, [_vp, C.POINTER(_vp), _sz]),
+    "gsl_sinterp_hip_shard_bounds": (None, [_sz, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "gsl_sinterp_hip_h2d_async": (_i, [_vp, _vp, _vp, _sz]),
+    "gsl_sinterp_hip_d2h_async": (_i, [_vp, _vp, _vp, _sz]),
+    "gsl_sinterp_hip_host_alloc": (_i, [C.POINTER(_vp), _sz]),
+    "gsl_sinterp_hip_host_free": (None, [_vp]),
     # --- include/gsl_sinterp.h part 1 (reference symbols)
     "simplex_tree_node_alloc": (_i, [_pt]),
     "simplex_tree_alloc": (_pt, [_i, _i]),
@@ -149,10 +164,16 @@ SIGNATURES = {
     "simplex_tree_device_eval_many": (_i, [_vp, _pm, _pv, _pi]),
     "simplex_tree_device_eval_resident": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "simplex_tree_device_ctx": (_vp, [_vp]),
+    "simplex_tree_device_alloc_multi": (_vp, [_pt, _pm, _pi, _i]),
+    "simplex_tree_device_n_devices": (_i, [_vp]),
+    "simplex_tree_device_transport": (C.c_char_p, [_vp]),
     # --- part 3
     "gsl_sinterp_alloc": (C.POINTER(gsl_sinterp), [_vp, _sz, _sz]),
     "gsl_sinterp_set_device": (_i, [C.POINTER(gsl_sinterp), _i]),
     "gsl_sinterp_set_shape": (_i, [C.POINTER(gsl_sinterp), _d]),
+    "gsl_sinterp_set_devices": (_i, [C.POINTER(gsl_sinterp), _i]),
+    "gsl_sinterp_set_device_list": (_i, [C.POINTER(gsl_sinterp), _pi, _i]),
+    "gsl_sinterp_n_devices": (_i, [C.POINTER(gsl_sinterp)]),
     "gsl_sinterp_set_tree_options": (_i, [C.POINTER(gsl_sinterp), _i, _vp]),
     "gsl_sinterp_init": (_i, [C.POINTER(gsl_sinterp), _pm, _pv]),
     "gsl_sinterp_name": (C.c_char_p, [C.POINTER(gsl_sinterp)]),
@@ -426,6 +447,13 @@ class SimplexTree:
             raise GslError(GSL_EFAILED, "simplex_tree_device_alloc")
         return DeviceTree(h)
 
+    def device_alloc_multi(self, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        h = lib().simplex_tree_device_alloc_multi(self._t, self._m(), arr, len(devices))
+        if not h:
+            raise GslError(GSL_EFAILED, "simplex_tree_device_alloc_multi")
+        return DeviceTree(h)
+
     def close(self):
         if self._t:
             lib().simplex_tree_free(self._t)
@@ -456,6 +484,12 @@ class DeviceTree:
     def eval_resident(self, d_targets, m, ttda, d_values, d_leaf):
         return lib().simplex_tree_device_eval_resident(self._h, d_targets, m, ttda, d_values, d_leaf)
 
+    def n_devices(self):
+        return lib().simplex_tree_device_n_devices(self._h)
+
+    def transport(self):
+        return lib().simplex_tree_device_transport(self._h).decode()
+
     def close(self):
         if self._h:
             lib().simplex_tree_device_free(self._h)
@@ -482,6 +516,16 @@ class Sinterp:
 
     def set_shape(self, eps):
         return lib().gsl_sinterp_set_shape(self._p, eps)
+
+    def set_devices(self, n):
+        return lib().gsl_sinterp_set_devices(self._p, n)
+
+    def set_device_list(self, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        return lib().gsl_sinterp_set_device_list(self._p, arr, len(devices))
+
+    def n_devices(self):
+        return lib().gsl_sinterp_n_devices(self._p)
 
     def set_tree_options(self, flags, rng):
         self._rng = rng

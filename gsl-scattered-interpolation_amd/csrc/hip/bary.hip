@@ -352,6 +352,7 @@ extern "C" int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
                                          const double *h_geom, void *d_records)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   REQUIRE(ctx, n_nodes > 0 && n_points >= 0, ST_EINVAL);
   REQUIRE(ctx, d_type && d_pidx && d_links && h_geom && d_records, ST_EFAULT);
   REQUIRE(ctx, ((uintptr_t)d_records & 63) == 0, ST_EINVAL);
@@ -391,6 +392,7 @@ extern "C" int gsl_sinterp_hip_tree_bind(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
                                          const double *d_response, void *d_leaftab)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   REQUIRE(ctx, n_nodes > 0 && n_points >= 0, ST_EINVAL);
   REQUIRE(ctx, d_pidx && d_leaftab && (d_response || n_points == 0), ST_EFAULT);
   REQUIRE(ctx, ((uintptr_t)d_leaftab & 31) == 0, ST_EINVAL);
@@ -406,6 +408,7 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
                                          long long *h_n_outside)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   REQUIRE(ctx, n_nodes > 0 && ttda >= 2, ST_EINVAL);
   REQUIRE(ctx, d_records && d_leaftab && h_scale && (m == 0 || (d_targets && d_values)), ST_EFAULT);
   if (h_n_outside) *h_n_outside = 0;

@@ -525,12 +525,8 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
     if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
     double *d_linv = d_diag + ((n + CB - 1) / CB) * (CB * CB);   /* 4 inverted 32x32 blocks */
     const size_t lds_diag = (size_t)(14 * PBLK) * sizeof(double), lds_trsm = (size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double);
-    static bool attr = false;
-    if (!attr) {
-      HIP_OK(ctx, hipFuncSetAttribute((const void *)chol_diag128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag));
-      HIP_OK(ctx, hipFuncSetAttribute((const void *)chol_trsm128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trsm));
-      attr = true;
-    }
+    { int ast = sinterp_func_lds(ctx, (const void *)chol_diag128_kernel, (int)lds_diag); if (ast) return ast; }
+    { int ast = sinterp_func_lds(ctx, (const void *)chol_trsm128_kernel, (int)lds_trsm); if (ast) return ast; }
     hipLaunchKernelGGL(chol_diag128_kernel, dim3(1), dim3(256), lds_diag, ctx->stream, A, lda, j0, d_info, d_diag, d_linv);
     const size_t below = n - j0 - w;
     if (below)
@@ -589,6 +585,8 @@ __global__ void chol_zero_info_kernel(int *info) { *info = 0; }
 static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, bool symmetric_input)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
+  EXCLUSIVE_SECTION(ctx);                         /* launches kernels that spin on sibling workgroups */
   REQUIRE(ctx, lda >= n, ST_EINVAL);
   REQUIRE(ctx, n == 0 || d_a, ST_EFAULT);
   if (h_info) *h_info = 0;
@@ -1178,6 +1176,7 @@ int sinterp_trsv(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt
 int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda, double *d_x, size_t ldx,
                                int nrhs)
 {
+  EXCLUSIVE_SECTION(ctx);
   void *d_tmp = NULL;
   int st = sinterp_workspace(ctx, (size_t)nrhs * ldx * sizeof(double), &d_tmp);
   if (st) return st;
@@ -1189,6 +1188,8 @@ int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double 
 extern "C" int gsl_sinterp_hip_cholesky_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda, double *d_x)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
+  EXCLUSIVE_SECTION(ctx);
   REQUIRE(ctx, lda >= n, ST_EINVAL);
   REQUIRE(ctx, n == 0 || (d_llt && d_x), ST_EFAULT);
   return sinterp_cholesky_svx_multi(ctx, n, d_llt, lda, d_x, n, 1);

@@ -57,6 +57,7 @@ struct gsl_sinterp_hip_ctx {
   size_t jumpt_bytes;
   const void *jump_rec;
   int jump_nodes, jump_G;
+  int excl_depth;           /* nesting of sinterp_exclusive_begin/end */
   char err[512];
 };
 
@@ -91,6 +92,29 @@ static inline int sinterp_fail(gsl_sinterp_hip_ctx *ctx, int status, const char 
   } while (0)
 
 #define LAUNCH_CHECK(ctx) HIP_OK(ctx, hipGetLastError())
+
+/* hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per
+   (kernel, device) pair (a process-wide flag would leave the second device of a process without it) */
+int sinterp_func_lds(gsl_sinterp_hip_ctx *ctx, const void *func, int bytes);
+
+/* Kernels that spin on other workgroups of their own launch (stream-K fix-up, dataflow sweeps, the
+   cooperative LU panel) need all their workgroups co-resident; two of them running at once on one
+   device (two contexts / streams) could each hold CUs while waiting for workgroups that cannot be
+   scheduled.  Every entry point that launches such kernels brackets its launches with these: a
+   process-wide per-device event chain orders the exclusive sections of ALL contexts of that device
+   one after another on the GPU (nestable; the outermost pair does the work). */
+int sinterp_exclusive_begin(gsl_sinterp_hip_ctx *ctx);
+int sinterp_exclusive_end(gsl_sinterp_hip_ctx *ctx);
+
+struct SinterpExclusive {      /* RAII form: every return path of an entry point leaves the section */
+  gsl_sinterp_hip_ctx *ctx;
+  int st;
+  explicit SinterpExclusive(gsl_sinterp_hip_ctx *c) : ctx(c), st(sinterp_exclusive_begin(c)) {}
+  ~SinterpExclusive() { if (st == ST_SUCCESS) (void)sinterp_exclusive_end(ctx); }
+  SinterpExclusive(const SinterpExclusive &) = delete;
+  SinterpExclusive &operator=(const SinterpExclusive &) = delete;
+};
+#define EXCLUSIVE_SECTION(ctx) SinterpExclusive _excl(ctx); if (_excl.st) return _excl.st
 
 /* grow-only workspace owned by the context */
 int sinterp_workspace(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);

@@ -660,12 +660,11 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   if (!b_is_kn && (n == 32 || n == 64) && k <= 64 && (k % 4) == 0 && k >= 4 && ((lda & 1) == 0) && ((ldb & 1) == 0) &&
       ((((uintptr_t)A) & 15) == 0) && ((((uintptr_t)B) & 15) == 0)) {
     const size_t lds = (size_t)(128 + n) * (k + 2) * sizeof(double);
-    static bool attr32 = false, attr64 = false;
     if (n == 32) {
-      if (!attr32) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_smallk_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr32 = true; }
+      { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_smallk_kernel<32>, 160 * 1024); if (ast) return ast; }
       hipLaunchKernelGGL(gemm_minus_smallk_kernel<32>, dim3((unsigned)g.tiles_m), dim3(256), lds, ctx->stream, g);
     } else {
-      if (!attr64) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_smallk_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr64 = true; }
+      { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_smallk_kernel<64>, 160 * 1024); if (ast) return ast; }
       hipLaunchKernelGGL(gemm_minus_smallk_kernel<64>, dim3((unsigned)g.tiles_m), dim3(256), lds, ctx->stream, g);
     }
     LAUNCH_CHECK(ctx);
@@ -714,18 +713,17 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       total64 = (unsigned long long)(tiles - x.dp_rounds * G) * x.steps;
       if (total64 < 0x7fffffffull) {
       x.total = (unsigned)total64; x.base = x.total / G; x.rem = x.total % G;
-      static bool attr_sk[3] = {false, false, false};
       if (cfg == 0) {
         const size_t lds = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);
-        if (!attr_sk[0]) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<256, 128, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_sk[0] = true; }
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<256, 128, 64, 64>, (int)lds); if (ast) return ast; }
         hipLaunchKernelGGL((gemm_minus_streamk_kernel<256, 128, 64, 64>), dim3(G), dim3(512), lds, ctx->stream, h, x);
       } else if (cfg == 1) {
         const size_t lds = (size_t)DM_STAGES * (128 + 128) * GT_BK * sizeof(double);
-        if (!attr_sk[1]) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<128, 128, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_sk[1] = true; }
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<128, 128, 64, 64>, (int)lds); if (ast) return ast; }
         hipLaunchKernelGGL((gemm_minus_streamk_kernel<128, 128, 64, 64>), dim3(G), dim3(256), lds, ctx->stream, h, x);
       } else {
         const size_t lds = (size_t)DM_STAGES * (64 + 64) * GT_BK * sizeof(double);
-        if (!attr_sk[2]) { HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_streamk_kernel<64, 64, 32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_sk[2] = true; }
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<64, 64, 32, 32>, (int)lds); if (ast) return ast; }
         hipLaunchKernelGGL((gemm_minus_streamk_kernel<64, 64, 32, 32>), dim3(G), dim3(256), lds, ctx->stream, h, x);
       }
       LAUNCH_CHECK(ctx);
@@ -743,21 +741,13 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
         grid8 = 2 * fr_ * (fr_ + 1) / 2 + ((unsigned)h.tiles_m - fr_) * (unsigned)h.tiles_n;
       }
       const size_t lds8 = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);   /* 144 KiB */
-      static bool attr8 = false;
-      if (!attr8) {
-        HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_dma_nt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-        attr8 = true;
-      }
+      { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_dma_nt_kernel<4>, (int)lds8); if (ast) return ast; }
       hipLaunchKernelGGL(gemm_minus_dma_nt_kernel<4>, dim3(grid8), dim3(512), lds8, ctx->stream, h);
       LAUNCH_CHECK(ctx);
       return ST_SUCCESS;
     }
     const size_t lds = (size_t)DM_STAGES * (128 + 128) * GT_BK * sizeof(double);     /* 96 KiB */
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIP_OK(ctx, hipFuncSetAttribute((const void *)gemm_minus_dma_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
+    { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_dma_nt_kernel<2>, (int)lds); if (ast) return ast; }
     hipLaunchKernelGGL(gemm_minus_dma_nt_kernel<2>, dim3(grid), dim3(256), lds, ctx->stream, g);
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
@@ -778,6 +768,8 @@ extern "C" int gsl_sinterp_hip_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, si
                                           size_t ldc, int lower_only)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
+  EXCLUSIVE_SECTION(ctx);
   REQUIRE(ctx, lda >= k && ldc >= n && ldb >= (b_is_kn ? n : k), ST_EINVAL);
   REQUIRE(ctx, (m == 0 || n == 0 || k == 0) || (d_a && d_b && d_c), ST_EFAULT);
   int st = sinterp_streamk_prepare(ctx);

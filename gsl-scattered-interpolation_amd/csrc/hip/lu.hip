@@ -561,6 +561,8 @@ extern "C" int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, dou
                                          int *h_signum)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
+  EXCLUSIVE_SECTION(ctx);
   REQUIRE(ctx, lda >= n && n < 2147483647ULL, ST_EINVAL);
   REQUIRE(ctx, n == 0 || (d_a && d_perm), ST_EFAULT);
   if (h_signum) *h_signum = 1;
@@ -614,6 +616,8 @@ extern "C" int gsl_sinterp_hip_lu_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const 
                                       const int *d_perm, double *d_x)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
+  EXCLUSIVE_SECTION(ctx);
   REQUIRE(ctx, lda >= n, ST_EINVAL);
   REQUIRE(ctx, n == 0 || (d_lu && d_perm && d_x), ST_EFAULT);
   if (n == 0) return ST_SUCCESS;

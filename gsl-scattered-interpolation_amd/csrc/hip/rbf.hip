@@ -442,6 +442,7 @@ extern "C" int gsl_sinterp_hip_rbf_fill(gsl_sinterp_hip_ctx *ctx, int kind, doub
                                         int dim, size_t xtda, double *d_phi, size_t lda)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && lda >= n, ST_EINVAL);
   REQUIRE(ctx, kind == GSL_SINTERP_RBF_GAUSSIAN || kind == GSL_SINTERP_RBF_TPS, ST_EINVAL);
   REQUIRE(ctx, n == 0 || (d_x && d_phi), ST_EFAULT);
@@ -474,6 +475,7 @@ extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, doub
                                         size_t ytda, double *d_s)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && ytda >= (size_t)dim, ST_EINVAL);
   REQUIRE(ctx, kind == GSL_SINTERP_RBF_GAUSSIAN || kind == GSL_SINTERP_RBF_TPS, ST_EINVAL);
   REQUIRE(ctx, m == 0 || (d_y && d_s && (n == 0 || (d_x && d_w))), ST_EFAULT);

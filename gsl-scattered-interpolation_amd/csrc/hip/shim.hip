@@ -51,6 +51,7 @@ extern "C" int gsl_sinterp_hip_ctx_create(gsl_sinterp_hip_ctx **out, int device,
 extern "C" int gsl_sinterp_hip_ctx_own_stream(gsl_sinterp_hip_ctx *ctx)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   if (ctx->owns_stream) return ST_SUCCESS;
   HIP_OK(ctx, hipSetDevice(ctx->device));
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
@@ -97,6 +98,7 @@ extern "C" const char *gsl_sinterp_hip_last_error(const gsl_sinterp_hip_ctx *ctx
 extern "C" int gsl_sinterp_hip_sync(gsl_sinterp_hip_ctx *ctx)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
   return ST_SUCCESS;
 }
@@ -114,6 +116,7 @@ extern "C" int gsl_sinterp_hip_free(gsl_sinterp_hip_ctx *ctx, void *d_ptr)
 {
   if (!d_ptr) return ST_SUCCESS;
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
   HIP_OK(ctx, hipFree(d_ptr));
   return ST_SUCCESS;
@@ -122,6 +125,7 @@ extern "C" int gsl_sinterp_hip_free(gsl_sinterp_hip_ctx *ctx, void *d_ptr)
 extern "C" int gsl_sinterp_hip_h2d(gsl_sinterp_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   if (!bytes) return ST_SUCCESS;
   HIP_OK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   /* pageable source: make reuse of h_src safe */
@@ -131,6 +135,7 @@ extern "C" int gsl_sinterp_hip_h2d(gsl_sinterp_hip_ctx *ctx, void *d_dst, const 
 extern "C" int gsl_sinterp_hip_d2h(gsl_sinterp_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   if (!bytes) return ST_SUCCESS;
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
   HIP_OK(ctx, hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
@@ -141,6 +146,7 @@ extern "C" int gsl_sinterp_hip_d2h(gsl_sinterp_hip_ctx *ctx, void *h_dst, const 
 extern "C" int gsl_sinterp_hip_timer_start(gsl_sinterp_hip_ctx *ctx)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   HIP_OK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   return ST_SUCCESS;
 }
@@ -148,9 +154,61 @@ extern "C" int gsl_sinterp_hip_timer_start(gsl_sinterp_hip_ctx *ctx)
 extern "C" int gsl_sinterp_hip_timer_stop(gsl_sinterp_hip_ctx *ctx, float *h_ms)
 {
   REQUIRE(ctx, ctx != NULL && h_ms != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   HIP_OK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_OK(ctx, hipEventSynchronize(ctx->ev1));
   HIP_OK(ctx, hipEventElapsedTime(h_ms, ctx->ev0, ctx->ev1));
+  return ST_SUCCESS;
+}
+
+#include <mutex>
+#define SINTERP_MAX_DEVICES 64
+namespace {
+struct FuncAttr { const void *func; unsigned long long done; int bytes; };
+std::mutex g_attr_mutex;
+FuncAttr g_attr[64];
+int g_attr_n = 0;
+
+struct DeviceChain { std::mutex mu; hipEvent_t ev; bool have; };
+DeviceChain g_chain[SINTERP_MAX_DEVICES];
+}
+
+int sinterp_func_lds(gsl_sinterp_hip_ctx *ctx, const void *func, int bytes)
+{
+  std::lock_guard<std::mutex> lock(g_attr_mutex);
+  const int dev = ctx->device;
+  FuncAttr *a = NULL;
+  for (int i = 0; i < g_attr_n; i++) if (g_attr[i].func == func) { a = &g_attr[i]; break; }
+  if (!a && g_attr_n < 64) { a = &g_attr[g_attr_n++]; a->func = func; a->done = 0; a->bytes = 0; }
+  if (a && dev < 64 && ((a->done >> dev) & 1ull) && a->bytes >= bytes) return ST_SUCCESS;
+  HIP_OK(ctx, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (a && dev < 64) { a->done = (a->bytes == bytes ? a->done : 0ull) | (1ull << dev); a->bytes = bytes; }
+  return ST_SUCCESS;
+}
+
+int sinterp_exclusive_begin(gsl_sinterp_hip_ctx *ctx)
+{
+  if (ctx->excl_depth++ > 0) return ST_SUCCESS;
+  if (ctx->device < 0 || ctx->device >= SINTERP_MAX_DEVICES) return ST_SUCCESS;
+  DeviceChain &c = g_chain[ctx->device];
+  c.mu.lock();                                            /* held until _end: launches of one section are not interleaved */
+  if (c.have) {
+    hipError_t e = hipStreamWaitEvent(ctx->stream, c.ev, 0);
+    if (e != hipSuccess) { ctx->excl_depth--; c.mu.unlock(); return sinterp_fail(ctx, ST_EFAILED, "hipStreamWaitEvent", e, __FILE__, __LINE__); }
+  }
+  return ST_SUCCESS;
+}
+
+int sinterp_exclusive_end(gsl_sinterp_hip_ctx *ctx)
+{
+  if (--ctx->excl_depth > 0) return ST_SUCCESS;
+  if (ctx->device < 0 || ctx->device >= SINTERP_MAX_DEVICES) return ST_SUCCESS;
+  DeviceChain &c = g_chain[ctx->device];
+  hipError_t e = hipSuccess;
+  if (!c.have) { e = hipEventCreateWithFlags(&c.ev, hipEventDisableTiming); c.have = (e == hipSuccess); }
+  if (c.have) e = hipEventRecord(c.ev, ctx->stream);
+  c.mu.unlock();
+  if (e != hipSuccess) return sinterp_fail(ctx, ST_EFAILED, "exclusive section: event", e, __FILE__, __LINE__);
   return ST_SUCCESS;
 }
 
@@ -295,6 +353,7 @@ extern "C" int gsl_sinterp_hip_synth_unit(gsl_sinterp_hip_ctx *ctx, uint64_t see
                                           double offset, double span, double *d_out, size_t count)
 {
   REQUIRE(ctx, ctx != NULL && d_out != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   if (!count) return ST_SUCCESS;
   size_t blocks = (count + 255) / 256;
   if (blocks > 4096) blocks = 4096;

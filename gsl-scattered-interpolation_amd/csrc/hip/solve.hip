@@ -143,6 +143,8 @@ extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, dou
                                          int dim, size_t xtda, double *d_phi, size_t lda, double *d_w, int *h_route)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
+  EXCLUSIVE_SECTION(ctx);
   REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && lda >= n, ST_EINVAL);
   REQUIRE(ctx, n == 0 || (d_x && d_phi && d_w), ST_EFAULT);
   if (h_route) *h_route = 0;

@@ -32,17 +32,134 @@ static int default_device(void)
   return s ? atoi(s) : 0;
 }
 
+/* GSL_SINTERP_DEVICES: "4" = devices 0..3, or an explicit list "0,2,5" (SURVEY.md section 5, config row).
+   Returns the number of entries written to list[], 0 when the variable is unset / unusable. */
+#define SINTERP_MAX_DEVICES 64
+static int env_device_list(int *list)
+{
+  const char *s = getenv("GSL_SINTERP_DEVICES");
+  if (!s || !*s) return 0;
+  if (!strchr(s, ',')) {
+    int n = atoi(s);
+    if (n < 1) return 0;
+    if (n > SINTERP_MAX_DEVICES) n = SINTERP_MAX_DEVICES;
+    for (int i = 0; i < n; i++) list[i] = i;
+    return n;
+  }
+  int n = 0;
+  while (*s && n < SINTERP_MAX_DEVICES) {
+    char *end = NULL;
+    long v = strtol(s, &end, 10);
+    if (end == s) break;
+    list[n++] = (int)v;
+    s = (*end == ',') ? end + 1 : end;
+  }
+  return n;
+}
+
+/* ======================================================================== */
+/* target shards over a device group (one host thread drives every member)   */
+/* ======================================================================== */
+typedef struct {
+  gsl_sinterp_hip_group *grp;
+  int n;
+  /* grow-only per-member device buffers of a shard: targets, values, leaf indices */
+  double *d_y[SINTERP_MAX_DEVICES], *d_s[SINTERP_MAX_DEVICES];
+  int *d_leaf[SINTERP_MAX_DEVICES];
+  size_t cap[SINTERP_MAX_DEVICES], cap_dim;
+  /* pinned host staging for the asynchronous copies */
+  void *h_stage;
+  size_t h_bytes;
+} shard_set;
+
+typedef int (*shard_eval_fn)(void *state, int member, const double *d_y, size_t m, double *d_s, int *d_leaf);
+
+static void shard_set_release(shard_set *ss)
+{
+  for (int i = 0; i < ss->n; i++) {
+    gsl_sinterp_hip_ctx *c = gsl_sinterp_hip_group_ctx(ss->grp, i);
+    gsl_sinterp_hip_free(c, ss->d_y[i]); gsl_sinterp_hip_free(c, ss->d_s[i]); gsl_sinterp_hip_free(c, ss->d_leaf[i]);
+    ss->d_y[i] = ss->d_s[i] = NULL; ss->d_leaf[i] = NULL; ss->cap[i] = 0;
+  }
+  gsl_sinterp_hip_host_free(ss->h_stage);
+  ss->h_stage = NULL; ss->h_bytes = 0;
+  gsl_sinterp_hip_group_destroy(ss->grp);
+  ss->grp = NULL; ss->n = 0;
+}
+
+/* Evaluate every row of y: member r takes the contiguous shard gsl_sinterp_hip_shard_bounds gives it.
+   All H2D copies, sweeps and D2H copies are enqueued before the first synchronisation, so the members
+   run concurrently; results come back per shard (no gather collective: each GPU copies its own shard to
+   the host).  Returns the number of targets whose leaf came back negative in *n_neg. */
+static int shard_eval_many(shard_set *ss, size_t dim, const gsl_matrix *y, gsl_vector *sv, int *leaf,
+                           shard_eval_fn fn, void *state, int want_leaf, size_t *n_neg)
+{
+  const size_t m = y->size1;
+  if (n_neg) *n_neg = 0;
+  if (m == 0) return GSL_SUCCESS;
+  const size_t o_s = m * dim * sizeof(double), o_l = o_s + m * sizeof(double), need = o_l + (want_leaf ? m * sizeof(int) : 0);
+  if (need > ss->h_bytes) {
+    gsl_sinterp_hip_host_free(ss->h_stage);
+    ss->h_stage = NULL; ss->h_bytes = 0;
+    if (gsl_sinterp_hip_host_alloc(&ss->h_stage, need) != GSL_SUCCESS) return GSL_ENOMEM;
+    ss->h_bytes = need;
+  }
+  double *h_y = (double *)ss->h_stage, *h_s = (double *)((char *)ss->h_stage + o_s);
+  int *h_l = want_leaf ? (int *)((char *)ss->h_stage + o_l) : NULL;
+  for (size_t k = 0; k < m; k++)
+    for (size_t c = 0; c < dim; c++) h_y[k * dim + c] = y->data[k * y->tda + c];
+
+  int st = GSL_SUCCESS;
+  for (int r = 0; r < ss->n && !st; r++) {
+    size_t first, cnt;
+    gsl_sinterp_hip_shard_bounds(m, ss->n, r, &first, &cnt);
+    if (!cnt) continue;
+    gsl_sinterp_hip_ctx *c = gsl_sinterp_hip_group_ctx(ss->grp, r);
+    if (cnt > ss->cap[r] || dim > ss->cap_dim) {
+      gsl_sinterp_hip_free(c, ss->d_y[r]); gsl_sinterp_hip_free(c, ss->d_s[r]); gsl_sinterp_hip_free(c, ss->d_leaf[r]);
+      ss->d_y[r] = ss->d_s[r] = NULL; ss->d_leaf[r] = NULL; ss->cap[r] = 0;
+      st = gsl_sinterp_hip_malloc(c, (void **)&ss->d_y[r], cnt * 3 * sizeof(double));   /* room for any dim <= 3 */
+      if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&ss->d_s[r], cnt * sizeof(double));
+      if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&ss->d_leaf[r], cnt * sizeof(int));
+      if (st) break;
+      ss->cap[r] = cnt; ss->cap_dim = 3;
+    }
+    st = gsl_sinterp_hip_h2d_async(c, ss->d_y[r], h_y + first * dim, cnt * dim * sizeof(double));
+    if (!st) st = fn(state, r, ss->d_y[r], cnt, ss->d_s[r], want_leaf ? ss->d_leaf[r] : NULL);
+    if (!st) st = gsl_sinterp_hip_d2h_async(c, h_s + first, ss->d_s[r], cnt * sizeof(double));
+    if (!st && want_leaf) st = gsl_sinterp_hip_d2h_async(c, h_l + first, ss->d_leaf[r], cnt * sizeof(int));
+    if (st) gsl_error(gsl_sinterp_hip_last_error(c), __FILE__, __LINE__, st);
+  }
+  for (int r = 0; r < ss->n; r++) {                      /* always drain every member, also after a failure */
+    int s2 = gsl_sinterp_hip_sync(gsl_sinterp_hip_group_ctx(ss->grp, r));
+    if (!st && s2) { st = s2; gsl_error(gsl_sinterp_hip_last_error(gsl_sinterp_hip_group_ctx(ss->grp, r)), __FILE__, __LINE__, st); }
+  }
+  if (st) return st;
+  for (size_t k = 0; k < m; k++) gsl_vector_set(sv, k, h_s[k]);
+  if (want_leaf) {
+    size_t neg = 0;
+    for (size_t k = 0; k < m; k++) { neg += h_l[k] < 0; if (leaf) leaf[k] = h_l[k]; }
+    if (n_neg) *n_neg = neg;
+  }
+  return GSL_SUCCESS;
+}
+
 /* ======================================================================== */
 /* simplex_tree_device                                                       */
 /* ======================================================================== */
 struct simplex_tree_device {
-  gsl_sinterp_hip_ctx *ctx;
+  gsl_sinterp_hip_ctx *ctx;        /* member 0 (the only one for a single-device mirror) */
   simplex_tree *tree; /* borrowed */
   int n_nodes, n_points;
-  void *d_records, *d_leaftab;
+  void *d_records, *d_leaftab;     /* member 0 */
   int *d_pidx;
   double scale[2];
   int response_bound;
+  /* multi-GPU mirror (simplex_tree_device_alloc_multi): every member holds its own packed records,
+     leaf table and vertex ids; ss.grp owns the contexts (ctx above aliases member 0's) */
+  shard_set ss;
+  void *m_records[SINTERP_MAX_DEVICES], *m_leaftab[SINTERP_MAX_DEVICES];
+  int *m_pidx[SINTERP_MAX_DEVICES];
 };
 
 gsl_sinterp_hip_ctx *simplex_tree_device_ctx(simplex_tree_device *dev) { return dev ? dev->ctx : NULL; }
@@ -50,6 +167,15 @@ gsl_sinterp_hip_ctx *simplex_tree_device_ctx(simplex_tree_device *dev) { return 
 void simplex_tree_device_free(simplex_tree_device *dev)
 {
   if (!dev) return;
+  if (dev->ss.grp) {
+    for (int i = 0; i < dev->ss.n; i++) {
+      gsl_sinterp_hip_ctx *c = gsl_sinterp_hip_group_ctx(dev->ss.grp, i);
+      gsl_sinterp_hip_free(c, dev->m_records[i]); gsl_sinterp_hip_free(c, dev->m_leaftab[i]); gsl_sinterp_hip_free(c, dev->m_pidx[i]);
+    }
+    shard_set_release(&dev->ss);                   /* destroys the members' contexts, dev->ctx among them */
+    free(dev);
+    return;
+  }
   if (dev->ctx) {
     gsl_sinterp_hip_free(dev->ctx, dev->d_records);
     gsl_sinterp_hip_free(dev->ctx, dev->d_leaftab);
@@ -124,6 +250,105 @@ simplex_tree_device *simplex_tree_device_alloc(simplex_tree *tree, gsl_matrix *d
   return dev;
 }
 
+/* Mirror `tree` on every device of the list.  The raw DAG arrays (node types, vertex ids, links, points:
+   SURVEY.md 8(e)'s ~17 MB at N = 50 000) go to member 0 over PCIe ONCE and are replicated with one
+   broadcast per array (RCCL over xGMI); every member then packs its own node records and jump table,
+   so all members evaluate from an identical, locally built mirror. */
+simplex_tree_device *simplex_tree_device_alloc_multi(simplex_tree *tree, gsl_matrix *data, const int *devices, int n_devices)
+{
+  if (n_devices == 1 && devices) return simplex_tree_device_alloc(tree, data, devices[0]);
+  if (!devices || n_devices < 1 || n_devices > SINTERP_MAX_DEVICES)
+    GSL_ERROR_NULL("simplex_tree_device_alloc_multi: bad device list", GSL_EINVAL);
+  if (!tree || tree->dim != 2) GSL_ERROR_NULL("simplex_tree_device_alloc_multi: need a 2-D tree", GSL_EINVAL);
+  if (tree->n_points > 0 && !data) GSL_ERROR_NULL("simplex_tree_device_alloc_multi: data matrix required", GSL_EINVAL);
+  const int n = tree->n_simplexes, np = tree->n_points;
+  for (int k = 0; k < n; k++)
+    if (tree->simplexes[k].points != 3 * k || tree->simplexes[k].links != 3 * k)
+      GSL_ERROR_NULL("simplex_tree_device_alloc_multi: unexpected node slot layout", GSL_ESANITY);
+  simplex_tree_device *dev = (simplex_tree_device *)calloc(1, sizeof *dev);
+  if (!dev) GSL_ERROR_NULL("simplex_tree_device_alloc_multi: out of memory", GSL_ENOMEM);
+  dev->tree = tree; dev->n_nodes = n; dev->n_points = np;
+  dev->scale[0] = gsl_vector_get(tree->scale, 0);
+  dev->scale[1] = gsl_vector_get(tree->scale, 1);
+  if (gsl_sinterp_hip_group_create(&dev->ss.grp, devices, n_devices) != GSL_SUCCESS) {
+    free(dev);
+    GSL_ERROR_NULL("simplex_tree_device_alloc_multi: cannot create the device group (GPU path has no CPU fallback)", GSL_EFAILED);
+  }
+  dev->ss.n = n_devices;
+  dev->ctx = gsl_sinterp_hip_group_ctx(dev->ss.grp, 0);
+
+  const size_t nb = (size_t)n * sizeof(int), pb = (size_t)(np > 0 ? np : 1) * 2 * sizeof(double);
+  int *h_type = (int *)malloc(nb);
+  double *h_pts = (double *)malloc(pb);
+  double geom[10];
+  int *d_type[SINTERP_MAX_DEVICES] = {0}, *d_links[SINTERP_MAX_DEVICES] = {0};
+  double *d_pts[SINTERP_MAX_DEVICES] = {0};
+  int st = (h_type && h_pts) ? GSL_SUCCESS : GSL_ENOMEM;
+  if (!st) {
+    for (int k = 0; k < n; k++) h_type[k] = (int)tree->simplexes[k].type;
+    for (int i = 0; i < np; i++) {
+      const double *row = data->data + tree->shuffle->data[i] * data->tda;
+      h_pts[2 * i] = row[0]; h_pts[2 * i + 1] = row[1];
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 2; j++) geom[2 * i + j] = gsl_matrix_get(tree->seed_points, i, j);
+    geom[6] = gsl_vector_get(tree->shift, 0); geom[7] = gsl_vector_get(tree->shift, 1);
+    geom[8] = dev->scale[0]; geom[9] = dev->scale[1];
+  }
+  for (int r = 0; r < n_devices && !st; r++) {
+    gsl_sinterp_hip_ctx *c = gsl_sinterp_hip_group_ctx(dev->ss.grp, r);
+    st = gsl_sinterp_hip_malloc(c, (void **)&d_type[r], nb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&dev->m_pidx[r], 3 * nb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_links[r], 3 * nb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_pts[r], pb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, &dev->m_records[r], (size_t)n * GSL_SINTERP_TREE_RECORD_BYTES);
+    if (!st) st = gsl_sinterp_hip_malloc(c, &dev->m_leaftab[r], (size_t)n * GSL_SINTERP_TREE_LEAFTAB_BYTES);
+  }
+  if (!st) {
+    gsl_sinterp_hip_ctx *c0 = dev->ctx;
+    st = gsl_sinterp_hip_h2d(c0, d_type[0], h_type, nb);
+    if (!st) st = gsl_sinterp_hip_h2d(c0, dev->m_pidx[0], tree->pidx, 3 * nb);
+    if (!st) st = gsl_sinterp_hip_h2d(c0, d_links[0], tree->links, 3 * nb);
+    if (!st && np > 0) st = gsl_sinterp_hip_h2d(c0, d_pts[0], h_pts, (size_t)np * 2 * sizeof(double));
+    /* model replication: the only collective of the path */
+    if (!st) st = gsl_sinterp_hip_group_broadcast(dev->ss.grp, (void *const *)d_type, nb);
+    if (!st) st = gsl_sinterp_hip_group_broadcast(dev->ss.grp, (void *const *)dev->m_pidx, 3 * nb);
+    if (!st) st = gsl_sinterp_hip_group_broadcast(dev->ss.grp, (void *const *)d_links, 3 * nb);
+    if (!st) st = gsl_sinterp_hip_group_broadcast(dev->ss.grp, (void *const *)d_pts, pb);
+  }
+  for (int r = 0; r < n_devices && !st; r++)
+    st = gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_group_ctx(dev->ss.grp, r), n, d_type[r], dev->m_pidx[r], d_links[r], np, d_pts[r],
+                                   geom, dev->m_records[r]);
+  for (int r = 0; r < n_devices; r++) {
+    gsl_sinterp_hip_ctx *c = gsl_sinterp_hip_group_ctx(dev->ss.grp, r);
+    int s2 = gsl_sinterp_hip_sync(c);
+    if (!st) st = s2;
+    gsl_sinterp_hip_free(c, d_type[r]); gsl_sinterp_hip_free(c, d_links[r]); gsl_sinterp_hip_free(c, d_pts[r]);
+  }
+  free(h_type); free(h_pts);
+  if (st != GSL_SUCCESS) {
+    gsl_error(gsl_sinterp_hip_last_error(dev->ctx), __FILE__, __LINE__, st);
+    simplex_tree_device_free(dev);
+    return NULL;
+  }
+  dev->d_records = dev->m_records[0]; dev->d_leaftab = dev->m_leaftab[0]; dev->d_pidx = dev->m_pidx[0];
+  return dev;
+}
+
+int simplex_tree_device_n_devices(const simplex_tree_device *dev) { return dev ? (dev->ss.grp ? dev->ss.n : 1) : 0; }
+const char *simplex_tree_device_transport(const simplex_tree_device *dev)
+{
+  return (dev && dev->ss.grp) ? gsl_sinterp_hip_group_transport(dev->ss.grp) : "none";
+}
+
+static int simplex_shard_eval(void *state, int member, const double *d_y, size_t m, double *d_s, int *d_leaf)
+{
+  simplex_tree_device *dev = (simplex_tree_device *)state;
+  int st = gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_group_ctx(dev->ss.grp, member), dev->n_nodes, dev->m_records[member],
+                                     dev->m_leaftab[member], dev->scale, d_y, m, 2, d_s, d_leaf, NULL);
+  return st == GSL_EDOM ? GSL_SUCCESS : st;
+}
+
 int simplex_tree_device_set_response(simplex_tree_device *dev, const gsl_vector *response)
 {
   if (!dev) GSL_ERROR("simplex_tree_device_set_response: null device tree", GSL_EFAULT);
@@ -133,6 +358,27 @@ int simplex_tree_device_set_response(simplex_tree_device *dev, const gsl_vector 
   double *h = (double *)malloc((size_t)(np > 0 ? np : 1) * sizeof(double));
   if (!h) GSL_ERROR("simplex_tree_device_set_response: out of memory", GSL_ENOMEM);
   for (int i = 0; i < np; i++) h[i] = gsl_vector_get(response, dev->tree->shuffle->data[i]);
+  if (dev->ss.grp) {
+    /* response (insertion order) -> member 0 -> one broadcast -> every member binds its own leaf table */
+    double *d_r[SINTERP_MAX_DEVICES] = {0};
+    const size_t rb = (size_t)(np > 0 ? np : 1) * sizeof(double);
+    int st = GSL_SUCCESS;
+    for (int r = 0; r < dev->ss.n && !st; r++) st = gsl_sinterp_hip_malloc(gsl_sinterp_hip_group_ctx(dev->ss.grp, r), (void **)&d_r[r], rb);
+    if (!st && np > 0) st = gsl_sinterp_hip_h2d(dev->ctx, d_r[0], h, (size_t)np * sizeof(double));
+    if (!st) st = gsl_sinterp_hip_group_broadcast(dev->ss.grp, (void *const *)d_r, rb);
+    for (int r = 0; r < dev->ss.n && !st; r++)
+      st = gsl_sinterp_hip_tree_bind(gsl_sinterp_hip_group_ctx(dev->ss.grp, r), dev->n_nodes, dev->m_pidx[r], np, d_r[r], dev->m_leaftab[r]);
+    for (int r = 0; r < dev->ss.n; r++) {
+      gsl_sinterp_hip_ctx *c = gsl_sinterp_hip_group_ctx(dev->ss.grp, r);
+      int s2 = gsl_sinterp_hip_sync(c);
+      if (!st) st = s2;
+      gsl_sinterp_hip_free(c, d_r[r]);
+    }
+    free(h);
+    HIP_TRY(st, dev->ctx);
+    dev->response_bound = 1;
+    return GSL_SUCCESS;
+  }
   double *d_resp = NULL;
   int st = gsl_sinterp_hip_malloc(dev->ctx, (void **)&d_resp, (size_t)(np > 0 ? np : 1) * sizeof(double));
   if (!st && np > 0) st = gsl_sinterp_hip_h2d(dev->ctx, d_resp, h, (size_t)np * sizeof(double));
@@ -165,6 +411,13 @@ int simplex_tree_device_eval_many(simplex_tree_device *dev, const gsl_matrix *ta
   const size_t m = targets->size1;
   if (values->size != m) GSL_ERROR("simplex_tree_device_eval_many: values length must equal target rows", GSL_EBADLEN);
   if (m == 0) return GSL_SUCCESS;
+  if (dev->ss.grp) {
+    size_t outside_n = 0;
+    int sst = shard_eval_many(&dev->ss, 2, targets, values, leaf, &simplex_shard_eval, dev, 1, &outside_n);
+    if (sst != GSL_SUCCESS) GSL_ERROR("simplex_tree_device_eval_many: sharded evaluation failed", sst);
+    if (outside_n) GSL_ERROR("simplex_tree_device_eval_many: target(s) outside the caging simplex", GSL_EDOM);
+    return GSL_SUCCESS;
+  }
 
   gsl_sinterp_hip_ctx *c = dev->ctx;
   double *h_y = (double *)malloc(m * 2 * sizeof(double));
@@ -200,11 +453,14 @@ int simplex_tree_device_eval_many(simplex_tree_device *dev, const gsl_matrix *ta
 /* ======================================================================== */
 typedef struct {
   int kind;
-  gsl_sinterp_hip_ctx *ctx;
+  gsl_sinterp_hip_ctx *ctx;   /* member 0: fill + factorisation + solves run here ("replicas only" for the solve) */
   size_t n, dim;
   double eps;
-  double *d_x; /* n x dim, packed */
-  double *d_w; /* n */
+  double *d_x; /* n x dim, packed  (member 0: start of the model buffer) */
+  double *d_w; /* n                (member 0: model buffer + n*dim)      */
+  /* device group (n_devices > 1): the model buffer [x | w] of every member; ss.grp owns the contexts */
+  shard_set ss;
+  double *m_model[SINTERP_MAX_DEVICES];
 } rbf_state;
 
 static void *rbf_alloc_kind(int kind, size_t dim, size_t size)
@@ -217,15 +473,26 @@ static void *rbf_alloc_kind(int kind, size_t dim, size_t size)
 static void *rbf_gauss_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_GAUSSIAN, dim, size); }
 static void *rbf_tps_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_TPS, dim, size); }
 
+static void rbf_release_devices(rbf_state *st)
+{
+  if (st->ss.grp) {
+    for (int r = 0; r < st->ss.n; r++) {
+      gsl_sinterp_hip_free(gsl_sinterp_hip_group_ctx(st->ss.grp, r), st->m_model[r]);
+      st->m_model[r] = NULL;
+    }
+    shard_set_release(&st->ss);
+  } else if (st->ctx) {
+    gsl_sinterp_hip_free(st->ctx, st->d_x);       /* one buffer: d_w points into it */
+    gsl_sinterp_hip_ctx_destroy(st->ctx);
+  }
+  st->ctx = NULL; st->d_x = st->d_w = NULL;
+}
+
 static void rbf_free(void *vstate)
 {
   rbf_state *st = (rbf_state *)vstate;
   if (!st) return;
-  if (st->ctx) {
-    gsl_sinterp_hip_free(st->ctx, st->d_x);
-    gsl_sinterp_hip_free(st->ctx, st->d_w);
-    gsl_sinterp_hip_ctx_destroy(st->ctx);
-  }
+  rbf_release_devices(st);
   free(st);
 }
 
@@ -233,9 +500,22 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
 {
   rbf_state *st = (rbf_state *)interp->state;
   const size_t n = st->n, dim = st->dim;
-  if (!st->ctx) {
-    if (gsl_sinterp_hip_ctx_create(&st->ctx, interp->device, NULL) != GSL_SUCCESS)
+  const int nd = interp->n_devices > 1 ? interp->n_devices : 1;
+  /* (re)build the device side when the requested device set changed */
+  int same = st->ctx != NULL && ((nd == 1 && !st->ss.grp) || (st->ss.grp && st->ss.n == nd));
+  if (same && st->ss.grp)
+    for (int r = 0; r < nd; r++) same = same && gsl_sinterp_hip_group_device(st->ss.grp, r) == interp->devices[r];
+  if (!same) {
+    rbf_release_devices(st);
+    if (nd > 1) {
+      if (gsl_sinterp_hip_group_create(&st->ss.grp, interp->devices, nd) != GSL_SUCCESS)
+        GSL_ERROR("gsl_sinterp_init: cannot create the device group (GPU path has no CPU fallback)", GSL_EFAILED);
+      st->ss.n = nd;
+      st->ctx = gsl_sinterp_hip_group_ctx(st->ss.grp, 0);
+    } else if (gsl_sinterp_hip_ctx_create(&st->ctx, interp->device, NULL) != GSL_SUCCESS) {
+      st->ctx = NULL;
       GSL_ERROR("gsl_sinterp_init: no usable HIP device (GPU path has no CPU fallback)", GSL_EFAILED);
+    }
   }
   gsl_sinterp_hip_ctx *c = st->ctx;
   st->eps = interp->shape > 0 ? interp->shape : 2.0 * pow((double)n, 1.0 / (double)dim);
@@ -247,19 +527,30 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
     for (size_t cdim = 0; cdim < dim; cdim++) h_x[i * dim + cdim] = x->data[i * x->tda + cdim];
     h_f[i] = gsl_vector_get(f, i);
   }
-  gsl_sinterp_hip_free(c, st->d_x); gsl_sinterp_hip_free(c, st->d_w);
-  st->d_x = st->d_w = NULL;
+  /* the model = [centres | weights], one buffer per member: N (d+1) 8 bytes, the broadcast payload */
+  const size_t model_bytes = n * (dim + 1) * sizeof(double);
+  int s = GSL_SUCCESS;
+  if (st->ss.grp) {
+    for (int r = 0; r < nd && !s; r++)
+      if (!st->m_model[r]) s = gsl_sinterp_hip_malloc(gsl_sinterp_hip_group_ctx(st->ss.grp, r), (void **)&st->m_model[r], model_bytes);
+    st->d_x = st->m_model[0];
+  } else if (!st->d_x) {
+    s = gsl_sinterp_hip_malloc(c, (void **)&st->d_x, model_bytes);
+  }
+  st->d_w = st->d_x ? st->d_x + n * dim : NULL;
   double *d_phi = NULL;
   int route = 0;
-  int s = gsl_sinterp_hip_malloc(c, (void **)&st->d_x, n * dim * sizeof(double));
-  if (!s) s = gsl_sinterp_hip_malloc(c, (void **)&st->d_w, n * sizeof(double));
   if (!s) s = gsl_sinterp_hip_malloc(c, (void **)&d_phi, n * n * sizeof(double));
   if (!s) s = gsl_sinterp_hip_h2d(c, st->d_x, h_x, n * dim * sizeof(double));
   if (!s) s = gsl_sinterp_hip_h2d(c, st->d_w, h_f, n * sizeof(double));
   /* fill + dense solve on the device: Cholesky (Gaussian), shifted-SPD Cholesky with a
      Woodbury correction or pivoted LU (thin-plate spline) -- csrc/hip/solve.hip */
   if (!s) s = gsl_sinterp_hip_rbf_solve(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, &route);
+  /* replicate the solved model: ONE broadcast of the weight vector (+ centres) */
+  if (!s && st->ss.grp) s = gsl_sinterp_hip_group_broadcast(st->ss.grp, (void *const *)st->m_model, model_bytes);
   if (!s) s = gsl_sinterp_hip_sync(c);
+  if (st->ss.grp)
+    for (int r = 1; r < nd; r++) { int s2 = gsl_sinterp_hip_sync(gsl_sinterp_hip_group_ctx(st->ss.grp, r)); if (!s) s = s2; }
   gsl_sinterp_hip_free(c, d_phi);
   free(h_x); free(h_f);
   if (s == GSL_EDOM) GSL_ERROR("gsl_sinterp_init: kernel matrix is not positive definite", GSL_EDOM);
@@ -273,9 +564,20 @@ static int rbf_eval_resident(const gsl_sinterp *interp, const double *d_y, size_
   (void)d_leaf;
   const rbf_state *st = (const rbf_state *)interp->state;
   if (!st->d_w) GSL_ERROR("gsl_sinterp_eval: interpolant not initialised", GSL_EINVAL);
+  /* resident buffers live on ONE device: member 0 evaluates them (shard resident targets yourself with
+     gsl_sinterp_hip_shard_bounds + one interpolant per device, as bench.py does per process) */
   HIP_TRY(gsl_sinterp_hip_rbf_eval(st->ctx, st->kind, st->eps, st->d_x, st->n, (int)st->dim, st->dim,
                                    st->d_w, d_y, m, ytda, d_s), st->ctx);
   return GSL_SUCCESS;
+}
+
+static int rbf_shard_eval(void *state, int member, const double *d_y, size_t m, double *d_s, int *d_leaf)
+{
+  (void)d_leaf;
+  rbf_state *st = (rbf_state *)state;
+  const double *model = st->m_model[member];
+  return gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_group_ctx(st->ss.grp, member), st->kind, st->eps, model, st->n, (int)st->dim,
+                                  st->dim, model + st->n * st->dim, d_y, m, st->dim, d_s);
 }
 
 static int rbf_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vector *sv, int *leaf)
@@ -284,6 +586,13 @@ static int rbf_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vec
   if (!st->d_w) GSL_ERROR("gsl_sinterp_eval_many: interpolant not initialised", GSL_EINVAL);
   const size_t m = y->size1, dim = st->dim;
   if (m == 0) return GSL_SUCCESS;
+  if (st->ss.grp) {
+    rbf_state *mst = (rbf_state *)interp->state;         /* staging buffers are grow-only caches inside the state */
+    int sst = shard_eval_many(&mst->ss, dim, y, sv, NULL, &rbf_shard_eval, mst, 0, NULL);
+    if (sst != GSL_SUCCESS) GSL_ERROR("gsl_sinterp_eval_many: sharded evaluation failed", sst);
+    if (leaf) for (size_t k = 0; k < m; k++) leaf[k] = -1;
+    return GSL_SUCCESS;
+  }
   gsl_sinterp_hip_ctx *c = st->ctx;
   double *h_y = (double *)malloc(m * dim * sizeof(double));
   double *h_s = (double *)malloc(m * sizeof(double));
@@ -348,7 +657,8 @@ static int simplex_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vect
   if (!st->tree) return GSL_ENOMEM;
   int s = simplex_tree_init(st->tree, st->x, NULL, NULL, interp->init_flags, interp->rng);
   if (s != GSL_SUCCESS) return s;
-  st->dev = simplex_tree_device_alloc(st->tree, st->x, interp->device);
+  st->dev = interp->n_devices > 1 ? simplex_tree_device_alloc_multi(st->tree, st->x, interp->devices, interp->n_devices)
+                                  : simplex_tree_device_alloc(st->tree, st->x, interp->device);
   if (!st->dev) return GSL_EFAILED;
   return simplex_tree_device_set_response(st->dev, f);
 }
@@ -390,6 +700,9 @@ gsl_sinterp *gsl_sinterp_alloc(const gsl_sinterp_type *T, size_t dim, size_t siz
   if (!interp) GSL_ERROR_NULL("failed to allocate space for sinterp struct", GSL_ENOMEM);
   interp->type = T; interp->dim = dim; interp->size = size;
   interp->device = default_device();
+  interp->n_devices = env_device_list(interp->devices);   /* GSL_SINTERP_DEVICES: count or list; 0 = single device */
+  if (interp->n_devices >= 1) interp->device = interp->devices[0];
+  else { interp->n_devices = 1; interp->devices[0] = interp->device; }
   interp->shape = 0.0; interp->init_flags = SIMPLEX_TREE_DEFAULT; interp->rng = NULL;
   interp->state = T->alloc(dim, size);
   if (!interp->state) {
@@ -404,8 +717,34 @@ int gsl_sinterp_set_device(gsl_sinterp *interp, int device)
   if (!interp) GSL_ERROR("gsl_sinterp_set_device: null interpolant", GSL_EFAULT);
   if (device < 0) GSL_ERROR("gsl_sinterp_set_device: negative ordinal", GSL_EINVAL);
   interp->device = device;
+  interp->n_devices = 1; interp->devices[0] = device;
   return GSL_SUCCESS;
 }
+
+/* Evaluate on `n_devices` GPUs (ordinals 0 .. n_devices-1): the next gsl_sinterp_init solves on the first,
+   replicates the model with one broadcast and gsl_sinterp_eval_many shards its targets. */
+int gsl_sinterp_set_devices(gsl_sinterp *interp, int n_devices)
+{
+  if (!interp) GSL_ERROR("gsl_sinterp_set_devices: null interpolant", GSL_EFAULT);
+  if (n_devices < 1 || n_devices > GSL_SINTERP_MAX_DEVICES) GSL_ERROR("gsl_sinterp_set_devices: bad device count", GSL_EINVAL);
+  for (int i = 0; i < n_devices; i++) interp->devices[i] = i;
+  interp->n_devices = n_devices; interp->device = 0;
+  return GSL_SUCCESS;
+}
+
+int gsl_sinterp_set_device_list(gsl_sinterp *interp, const int *devices, int n_devices)
+{
+  if (!interp || !devices) GSL_ERROR("gsl_sinterp_set_device_list: null argument", GSL_EFAULT);
+  if (n_devices < 1 || n_devices > GSL_SINTERP_MAX_DEVICES) GSL_ERROR("gsl_sinterp_set_device_list: bad device count", GSL_EINVAL);
+  for (int i = 0; i < n_devices; i++) {
+    if (devices[i] < 0) GSL_ERROR("gsl_sinterp_set_device_list: negative ordinal", GSL_EINVAL);
+    interp->devices[i] = devices[i];
+  }
+  interp->n_devices = n_devices; interp->device = devices[0];
+  return GSL_SUCCESS;
+}
+
+int gsl_sinterp_n_devices(const gsl_sinterp *interp) { return interp ? interp->n_devices : 0; }
 
 int gsl_sinterp_set_shape(gsl_sinterp *interp, double eps)
 {

@@ -162,11 +162,18 @@ int simplex_tree_device_eval_many(simplex_tree_device *dev, const gsl_matrix *ta
 int simplex_tree_device_eval_resident(simplex_tree_device *dev, const double *d_targets, size_t m,
                                       size_t ttda, double *d_values, simplex_index *d_leaf);
 gsl_sinterp_hip_ctx *simplex_tree_device_ctx(simplex_tree_device *dev);
+/* Mirror on several GPUs: the raw DAG arrays are replicated with one broadcast per array, every member
+   packs its own records; eval_many shards the targets (eval_resident uses the first device). */
+simplex_tree_device *simplex_tree_device_alloc_multi(simplex_tree *tree, gsl_matrix *data, const int *devices,
+                                                     int n_devices);
+int simplex_tree_device_n_devices(const simplex_tree_device *dev);
+const char *simplex_tree_device_transport(const simplex_tree_device *dev);   /* "rccl" | "peer-copy" | "none" */
 
 /* ======================================================================== */
 /* Part 3: gsl_sinterp facade                                                */
 /* ======================================================================== */
 typedef struct gsl_sinterp_struct gsl_sinterp;
+#define GSL_SINTERP_MAX_DEVICES 64
 
 typedef struct {
   const char *name;
@@ -188,6 +195,8 @@ struct gsl_sinterp_struct {
   int init_flags;    /* SIMPLEX_TREE_* flags (linear simplex type)            */
   gsl_rng *rng;      /* insertion-order rng (linear simplex type), may be NULL */
   void *state;
+  int n_devices;     /* > 1: the model is replicated over devices[] and eval_many shards its targets */
+  int devices[GSL_SINTERP_MAX_DEVICES];
 };
 
 extern const gsl_sinterp_type *gsl_sinterp_rbf_gaussian;
@@ -196,6 +205,13 @@ extern const gsl_sinterp_type *gsl_sinterp_linear_simplex;
 
 gsl_sinterp *gsl_sinterp_alloc(const gsl_sinterp_type *T, size_t dim, size_t size);
 int gsl_sinterp_set_device(gsl_sinterp *interp, int device);
+/* Multi-GPU: solve on the first device, ONE broadcast of the model (RCCL over xGMI),
+   targets of gsl_sinterp_eval_many sharded contiguously over the devices, each shard copied back by its
+   own GPU.  set_devices(n) = ordinals 0..n-1; the environment variable GSL_SINTERP_DEVICES ("4" or
+   "0,2,5") sets the default at alloc time (GSL_SINTERP_DEVICE the single-device default). */
+int gsl_sinterp_set_devices(gsl_sinterp *interp, int n_devices);
+int gsl_sinterp_set_device_list(gsl_sinterp *interp, const int *devices, int n_devices);
+int gsl_sinterp_n_devices(const gsl_sinterp *interp);
 int gsl_sinterp_set_shape(gsl_sinterp *interp, double eps);
 int gsl_sinterp_set_tree_options(gsl_sinterp *interp, int init_flags, gsl_rng *rng);
 int gsl_sinterp_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *f);

@@ -56,6 +56,32 @@ int gsl_sinterp_hip_d2h(gsl_sinterp_hip_ctx *ctx, void *h_dst, const void *d_src
 int gsl_sinterp_hip_timer_start(gsl_sinterp_hip_ctx *ctx);
 int gsl_sinterp_hip_timer_stop(gsl_sinterp_hip_ctx *ctx, float *h_ms);
 
+/* ---- device groups: target shards over several GPUs of one node -------- */
+/* One context per listed device (each on a private stream, so one host thread keeps all devices
+   busy) and ONE collective: gsl_sinterp_hip_group_broadcast replicates a model buffer from member 0
+   to every member -- ncclBroadcast over xGMI on a communicator made by ncclCommInitAll (RCCL is
+   bound with dlopen when the first multi-device group is created).  A list that names one ordinal
+   twice (one-GPU test boxes) or GSL_SINTERP_NO_RCCL=1 replicates with hipMemcpyPeerAsync instead;
+   gsl_sinterp_hip_group_transport says which ("rccl" / "peer-copy" / "none").  There is no
+   reduction and no all-to-all on the path; the factorisation runs on member 0 only. */
+typedef struct gsl_sinterp_hip_group gsl_sinterp_hip_group;
+int gsl_sinterp_hip_group_create(gsl_sinterp_hip_group **grp, const int *devices, int n_devices);
+void gsl_sinterp_hip_group_destroy(gsl_sinterp_hip_group *grp);
+int gsl_sinterp_hip_group_size(const gsl_sinterp_hip_group *grp);
+int gsl_sinterp_hip_group_device(const gsl_sinterp_hip_group *grp, int member);
+gsl_sinterp_hip_ctx *gsl_sinterp_hip_group_ctx(gsl_sinterp_hip_group *grp, int member);
+const char *gsl_sinterp_hip_group_transport(const gsl_sinterp_hip_group *grp);
+const char *gsl_sinterp_hip_group_last_error(const gsl_sinterp_hip_group *grp);
+/* d_bufs[i]: `bytes` bytes on member i; member 0's content goes to all (stream ordered, asynchronous) */
+int gsl_sinterp_hip_group_broadcast(gsl_sinterp_hip_group *grp, void *const *d_bufs, size_t bytes);
+/* the shard rule: contiguous ceil(m/world)-sized shards, every target exactly once */
+void gsl_sinterp_hip_shard_bounds(size_t m_total, int world, int rank, size_t *first, size_t *count);
+/* asynchronous copies on the context's stream + pinned host staging for them */
+int gsl_sinterp_hip_h2d_async(gsl_sinterp_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int gsl_sinterp_hip_d2h_async(gsl_sinterp_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int gsl_sinterp_hip_host_alloc(void **h_ptr, size_t bytes);
+void gsl_sinterp_hip_host_free(void *h_ptr);
+
 /* ---- barycentric evaluation over a host-built Delaunay history DAG ------- */
 /* One 64-byte record per DAG node (see DESIGN.md "HBM layout"). */
 #define GSL_SINTERP_TREE_RECORD_BYTES 64
