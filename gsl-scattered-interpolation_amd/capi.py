@@ -115,6 +115,8 @@ SIGNATURES = {
     "gsl_sinterp_hip_tree_pack": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _pd, _vp]),
     "gsl_sinterp_hip_tree_bind": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "gsl_sinterp_hip_bary_eval": (_i, [_vp, _i, _vp, _vp, _pd, _vp, _sz, _sz, _vp, _vp, C.POINTER(C.c_longlong)]),
+    "gsl_sinterp_hip_tree_check": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _pd, _i, C.POINTER(C.c_longlong),
+                                        C.POINTER(C.c_longlong), _pi]),
     "gsl_sinterp_hip_rbf_fill": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz]),
     "gsl_sinterp_hip_cholesky_decomp1": (_i, [_vp, _sz, _vp, _sz, _pi]),
     "gsl_sinterp_hip_cholesky_svx": (_i, [_vp, _sz, _vp, _sz, _vp]),
@@ -164,6 +166,7 @@ SIGNATURES = {
     "simplex_tree_device_eval_many": (_i, [_vp, _pm, _pv, _pi]),
     "simplex_tree_device_eval_resident": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "simplex_tree_device_ctx": (_vp, [_vp]),
+    "simplex_tree_check_device": (_i, [_pt, _pm, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "simplex_tree_device_alloc_multi": (_vp, [_pt, _pm, _pi, _i]),
     "simplex_tree_device_n_devices": (_i, [_vp]),
     "simplex_tree_device_transport": (C.c_char_p, [_vp]),
@@ -446,6 +449,12 @@ class SimplexTree:
         if not h:
             raise GslError(GSL_EFAILED, "simplex_tree_device_alloc")
         return DeviceTree(h)
+
+    def check_device(self, device=0):
+        """(verdict, leaf_violations, delaunay_violations): check_leaf_nodes + check_delaunay on the GPU."""
+        lv, dv = C.c_longlong(0), C.c_longlong(0)
+        ok = lib().simplex_tree_check_device(self._t, self._m(), device, C.byref(lv), C.byref(dv))
+        return ok, lv.value, dv.value
 
     def device_alloc_multi(self, devices):
         arr = (C.c_int * len(devices))(*devices)

@@ -448,6 +448,58 @@ int simplex_tree_device_eval_many(simplex_tree_device *dev, const gsl_matrix *ta
   return GSL_SUCCESS;
 }
 
+/* reference: check_leaf_nodes / check_delaunay (linear_simplex_integrity_check.c:121-168) */
+int simplex_tree_check_device(simplex_tree *tree, gsl_matrix *data, int device, long long *leaf_violations,
+                              long long *delaunay_violations)
+{
+  if (leaf_violations) *leaf_violations = 0;
+  if (delaunay_violations) *delaunay_violations = 0;
+  if (!tree || tree->dim != 2) GSL_ERROR_VAL("simplex_tree_check_device: need a 2-D tree", GSL_EINVAL, -GSL_EINVAL);
+  if (tree->n_points > 0 && !data) GSL_ERROR_VAL("simplex_tree_check_device: data matrix required", GSL_EINVAL, -GSL_EINVAL);
+  const int n = tree->n_simplexes, np = tree->n_points;
+  for (int k = 0; k < n; k++)
+    if (tree->simplexes[k].points != 3 * k || tree->simplexes[k].links != 3 * k)
+      GSL_ERROR_VAL("simplex_tree_check_device: unexpected node slot layout", GSL_ESANITY, -GSL_ESANITY);
+  gsl_sinterp_hip_ctx *c = NULL;
+  if (gsl_sinterp_hip_ctx_create(&c, device, NULL) != GSL_SUCCESS)
+    GSL_ERROR_VAL("simplex_tree_check_device: no usable HIP device (GPU path has no CPU fallback)", GSL_EFAILED, -GSL_EFAILED);
+  const size_t nb = (size_t)n * sizeof(int), pb = (size_t)(np > 0 ? np : 1) * 2 * sizeof(double);
+  int *h_type = (int *)malloc(nb);
+  double *h_pts = (double *)malloc(pb);
+  int *d_type = NULL, *d_pidx = NULL, *d_links = NULL;
+  double *d_pts = NULL, geom[10];
+  long long lv = 0, dv = 0;
+  int st = (h_type && h_pts) ? GSL_SUCCESS : GSL_ENOMEM;
+  if (!st) {
+    for (int k = 0; k < n; k++) h_type[k] = (int)tree->simplexes[k].type;
+    for (int i = 0; i < np; i++) {
+      const double *row = data->data + tree->shuffle->data[i] * data->tda;
+      h_pts[2 * i] = row[0]; h_pts[2 * i + 1] = row[1];
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 2; j++) geom[2 * i + j] = gsl_matrix_get(tree->seed_points, i, j);
+    geom[6] = gsl_vector_get(tree->shift, 0); geom[7] = gsl_vector_get(tree->shift, 1);
+    geom[8] = gsl_vector_get(tree->scale, 0); geom[9] = gsl_vector_get(tree->scale, 1);
+    st = gsl_sinterp_hip_malloc(c, (void **)&d_type, nb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_pidx, 3 * nb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_links, 3 * nb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_pts, pb);
+    if (!st) st = gsl_sinterp_hip_h2d(c, d_type, h_type, nb);
+    if (!st) st = gsl_sinterp_hip_h2d(c, d_pidx, tree->pidx, 3 * nb);
+    if (!st) st = gsl_sinterp_hip_h2d(c, d_links, tree->links, 3 * nb);
+    if (!st && np > 0) st = gsl_sinterp_hip_h2d(c, d_pts, h_pts, (size_t)np * 2 * sizeof(double));
+    if (!st) st = gsl_sinterp_hip_tree_check(c, n, d_type, d_pidx, d_links, np, d_pts, geom, 3, &lv, &dv, NULL);
+  }
+  if (st) gsl_error(gsl_sinterp_hip_last_error(c), __FILE__, __LINE__, st);
+  gsl_sinterp_hip_free(c, d_type); gsl_sinterp_hip_free(c, d_pidx); gsl_sinterp_hip_free(c, d_links); gsl_sinterp_hip_free(c, d_pts);
+  gsl_sinterp_hip_ctx_destroy(c);
+  free(h_type); free(h_pts);
+  if (st) return -st;
+  if (leaf_violations) *leaf_violations = lv;
+  if (delaunay_violations) *delaunay_violations = dv;
+  return (lv == 0 && dv == 0) ? 1 : 0;
+}
+
 /* ======================================================================== */
 /* RBF types                                                                 */
 /* ======================================================================== */

@@ -169,6 +169,14 @@ simplex_tree_device *simplex_tree_device_alloc_multi(simplex_tree *tree, gsl_mat
 int simplex_tree_device_n_devices(const simplex_tree_device *dev);
 const char *simplex_tree_device_transport(const simplex_tree_device *dev);   /* "rccl" | "peer-copy" | "none" */
 
+/* check_leaf_nodes + check_delaunay of the reference (interpolation/linear_simplex_integrity_check.c:121-168;
+   there an O(N^3) debug pass after every insertion) as two GPU kernels over the finished tree: O(leaves) and
+   O(leaves x N).  Returns 1 when every predicate holds -- check_delaunay's own return convention (:162-168) --
+   0 when a violation was found (counts in *leaf_violations / *delaunay_violations, either may be NULL), and a
+   negative value (-GSL status, raised through the handler) when the check could not run. */
+int simplex_tree_check_device(simplex_tree *tree, gsl_matrix *data, int device, long long *leaf_violations,
+                              long long *delaunay_violations);
+
 /* ======================================================================== */
 /* Part 3: gsl_sinterp facade                                                */
 /* ======================================================================== */

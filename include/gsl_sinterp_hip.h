@@ -20,6 +20,8 @@
  *   cholesky_svx            linalg/cholesky.c:163-185 (gsl_linalg_cholesky_svx)
  *   lu_decomp / lu_svx      linalg/lu.c:59-124, :166-201 (gsl_linalg_LU_decomp / _svx)
  *   rbf_eval                (no reference code) s(y) = sum_j w_j phi(|y-x_j|)
+ *   tree_check              interpolation/linear_simplex_integrity_check.c:62-119 (_check_leaf_nodes),
+ *                           :134-160 (_check_delaunay)
  */
 #ifndef GSL_SINTERP_HIP_H
 #define GSL_SINTERP_HIP_H
@@ -107,6 +109,17 @@ int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void 
                               const void *d_leaftab, const double *h_scale,
                               const double *d_targets, size_t m, size_t ttda, double *d_values,
                               int *d_leaf, long long *h_n_outside);
+
+/* Device-side integrity checks of a DAG given as raw arrays (same arguments as tree_pack):
+   what & 1: _check_leaf_nodes  (interpolation/linear_simplex_integrity_check.c:62-119), one thread per leaf;
+   what & 2: _check_delaunay    (:134-160; circumsphere per linear_simplex.c:555-605), leaves x points.
+   Counts of violating leaves / (leaf, point) pairs come back in *h_leaf_violations / *h_delaunay_violations
+   (0 = the reference's asserts would all hold); h_first[3] (may be NULL) = first bad leaf of either check
+   and one witness point, -1 when clean.  Synchronises the stream. */
+int gsl_sinterp_hip_tree_check(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type, const int *d_pidx,
+                               const int *d_links, int n_points, const double *d_points, const double *h_geom,
+                               int what, long long *h_leaf_violations, long long *h_delaunay_violations,
+                               int *h_first);
 
 /* ---- RBF: fill, dense solve, evaluation sweep ----------------------------- */
 int gsl_sinterp_hip_rbf_fill(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x,
