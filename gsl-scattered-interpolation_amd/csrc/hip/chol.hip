@@ -195,15 +195,17 @@ extern "C" int gsl_sinterp_hip_debug_diag_ts(unsigned long long *out) { return (
    shadow (a wave issues in order: the FMAs are interleaved by hand between the ~8 dependent chain
    ops, sched_barrier pins the order).  Only the k = J term needs a readlane. */
 template <int J, int SLOT>
-__device__ __forceinline__ void potrf32_fill(const double (&a)[CB], const double (&rp)[CB], double rlast, double (&p)[4])
+__device__ __forceinline__ void potrf32_fill(const double (&a)[CB], const double (&rp)[CB], double rlast, double (&p)[2])
 {
   /* partial dot product of column J+1: terms k < J-1 use row entries fetched one column ago (rp), the
-     term k = J-1 the entry fetched at the start of this column (rlast), consumed last; four accumulators */
+     term k = J-1 the entry fetched at the start of this column (rlast), consumed last; two accumulators
+     (the wave issues in order and an fp64 FMA occupies the VALU for 4 cycles: two chains already hide its
+     latency, and every extra accumulator is one more add on the dependent path into the next column) */
   if constexpr (J + 1 < CB && SLOT >= 2 && SLOT <= 6 && J >= 2) {
 #pragma unroll
-    for (int k = ((SLOT - 2) * (J - 1)) / 5; k < ((SLOT - 1) * (J - 1)) / 5; k++) p[k & 3] = fma(-a[k], rp[k], p[k & 3]);
+    for (int k = ((SLOT - 2) * (J - 1)) / 5; k < ((SLOT - 1) * (J - 1)) / 5; k++) p[k & 1] = fma(-a[k], rp[k], p[k & 1]);
   }
-  if constexpr (J + 1 < CB && SLOT == 7 && J >= 1) p[(J - 1) & 3] = fma(-a[J - 1], rlast, p[(J - 1) & 3]);
+  if constexpr (J + 1 < CB && SLOT == 7 && J >= 1) p[(J - 1) & 1] = fma(-a[J - 1], rlast, p[(J - 1) & 1]);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -231,17 +233,22 @@ __device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double c
         if (k + 1 < CB) rn[k + 1] = t.y;
       }
     }
-    const bool ok = d > 0.0;                            /* cholesky.c:120-123 */
-    badcol = (!ok && badcol == 0) ? J + 1 : badcol;
-    d = ok ? d : 1.0;
+    /* cholesky.c:120-123: a pivot <= 0 is RECORDED (first failing column wins), off the dependent chain: the
+       rsq below then yields inf / NaN, which flows through the rest of the block; the caller reports GSL_EDOM
+       and the content of a failed factorisation is unspecified (as in the reference, which stops mid-way).
+       (the test itself is issued after the rsq, below) */
     /* 1/sqrt(d) = y0 (1 - r)^(-1/2), r = 1 - d y0^2 with the v_rsq_f64 seed y0 (|r| <~ 2^-21):
        y0 (1 + r/2 + 3 r^2/8) is exact to r^3 ~ 1e-19 -- four dependent ops after the seed instead
-       of the seven of a Newton step plus correction.  sqrt(d) = d/sqrt(d) with one residual
-       correction, off the critical path.  Both end within an ulp or two of cholesky.c:125-126's
-       sqrt and divide. */
-    double p[4] = {0.0, 0.0, 0.0, 0.0};
+       of the seven of a Newton step plus correction.  The diagonal entry sqrt(d) = d / sqrt(d) is the
+       SAME product v * inv every row forms (lane J holds v = d), so no lane needs a special case; it
+       ends within ~2 ulp of cholesky.c:125-126's sqrt (a separate residual correction for that one
+       entry cost 9 instructions per column on the wave's in-order issue path). */
+    double p[2] = {0.0, 0.0};
     if constexpr (J + 1 < CB) p[0] = a[J + 1];
     const double y0 = __builtin_amdgcn_rsq(d);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool ok = d > 0.0;                            /* in the latency shadow of the rsq */
+    badcol = (!ok && badcol == 0) ? J + 1 : badcol;
     potrf32_fill<J, 0>(a, rp, rlast, p);
     const double t = d * y0;
     potrf32_fill<J, 1>(a, rp, rlast, p);
@@ -251,14 +258,12 @@ __device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double c
     potrf32_fill<J, 3>(a, rp, rlast, p);
     const double inv = fma(u, s1, y0);
     potrf32_fill<J, 4>(a, rp, rlast, p);
-    const double an = v * inv, sd0 = d * inv;
+    a[J] = v * inv;
     potrf32_fill<J, 5>(a, rp, rlast, p);
-    const double sd = fma(fma(-sd0, sd0, d), 0.5 * inv, sd0);
-    potrf32_fill<J, 6>(a, rp, rlast, p);
-    a[J] = (lane == J) ? sd : an;
     colp[J * cstride] = a[J];                           /* column J of L (row reads of later columns) / of L^-1 */
+    potrf32_fill<J, 6>(a, rp, rlast, p);
     potrf32_fill<J, 7>(a, rp, rlast, p);
-    potrf32_cols<J + 1>(a, lane, (p[0] + p[1]) + (p[2] + p[3]), badcol, D, colp, cstride, rn);
+    potrf32_cols<J + 1>(a, lane, p[0] + p[1], badcol, D, colp, cstride, rn);
   }
 }
 
@@ -291,34 +296,44 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
   __syncthreads();
   TSTAMP(1);
 
-  for (int jb = 0; jb < 4; jb++) {
+  /* Schedule.  The dependent chain is potrf32(0) -> TRSM of column 0 -> update of block (1,1) -> potrf32(1) -> ...;
+     a potrf32 occupies ONE wave for ~6 us.  Everything that is not on that chain -- the updates of the blocks
+     below the next diagonal block -- is done by waves 1..3 WHILE wave 0 factors the next diagonal block:
+         P(0) | T(0) | U1(0) | P(1) || U2(0) | T(1) | U1(1) | P(2) || U2(1) | T(2) | U1(2) | P(3)
+     T(jb): X = B Dinv^T for the blocks below D_jb; U1(jb): block (jb+1,jb+1) -= blk blk^T (its three lower
+     fragments, one per wave); U2(jb): the remaining blocks (bi >= jb+2) -= blk(bi,jb) blk(bj,jb)^T. */
+  auto potrf_block = [&](int jb) {
     double *D = S + pblk(jb, jb);
-    TSTAMP(2 + jb * 4);
-    if (wave == 0) {
-      /* potrf32 (see potrf32_cols).  Lanes 0..31 hold the rows of the diagonal block.  Lanes 32..63
-         produce its inverse with the SAME instruction stream: column c of L^-1 obeys
-            x_c[J] = (I[J][c] - sum_{k<J} L[J][k] x_c[k]) / L[J][J],
-         which is the left-looking update of a "row" whose data is row c of the identity. */
-      const bool is_row = lane < CB;
-      const int c = lane - CB;
-      double a[CB];
+    /* potrf32 (see potrf32_cols).  Lanes 0..31 hold the rows of the diagonal block.  Lanes 32..63
+       produce its inverse with the SAME instruction stream: column c of L^-1 obeys
+          x_c[J] = (I[J][c] - sum_{k<J} L[J][k] x_c[k]) / L[J][J],
+       which is the left-looking update of a "row" whose data is row c of the identity. */
+    const bool is_row = lane < CB;
+    const int c = lane - CB;
+    double a[CB];
 #pragma unroll
-      for (int k = 0; k < CB; k++) a[k] = is_row ? ((k <= lane) ? D[lane * PQ + k] : 0.0) : ((k == c) ? 1.0 : 0.0);
-      double *colp = is_row ? D + lane * PQ : Dv + jb * PBLK + c;   /* entry J of this lane's vector: colp[J * cstride] */
-      const int cstride = is_row ? 1 : PQ;
-      int badcol = 0;
-      double r0[CB];                                      /* nothing prefetched before column 0 */
-      potrf32_cols<0>(a, lane, a[0], badcol, D, colp, cstride, r0);
-      if (is_row) {
-#pragma unroll
-        for (int k = 0; k < CB; k++) D[lane * PQ + k] = (k <= lane) ? a[k] : 0.0;
-      }
-      if (badcol && lane == 0) atomicCAS(info, 0, (int)(j0 + jb * 32 + badcol));
-    }
-    __syncthreads();
-    TSTAMP(3 + jb * 4);
-    /* rows below: X = B Dinv^T on MFMA, one 16-row strip (both column fragments) per unit; Dinv is
-       lower triangular, so the first 16 columns need K = 16 only */
+    for (int k = 0; k < CB; k++) a[k] = is_row ? ((k <= lane) ? D[lane * PQ + k] : 0.0) : ((k == c) ? 1.0 : 0.0);
+    double *colp = is_row ? D + lane * PQ : Dv + jb * PBLK + c;   /* entry J of this lane's vector: colp[J * cstride] */
+    const int cstride = is_row ? 1 : PQ;
+    int badcol = 0;
+    double r0[CB];                                      /* nothing prefetched before column 0 */
+    potrf32_cols<0>(a, lane, a[0], badcol, D, colp, cstride, r0);
+    /* every column was written to D as it was produced (colp); the strict upper triangle of a diagonal
+       block is never read afterwards (TRSM uses Dv, the write-back masks k <= r) */
+    if (badcol && lane == 0) atomicCAS(info, 0, (int)(j0 + jb * 32 + badcol));
+  };
+  auto update_frag = [&](int jb, int bi, int bj, int f) {
+    double *Cb = S + pblk(bi, bj);
+    double4_t c = frag_load(Cb, f >> 1, f & 1, lane);
+    c = frag_nt(S + pblk(bi, jb), S + pblk(bj, jb), f >> 1, f & 1, lane, c, -1.0);
+    frag_store(Cb, f >> 1, f & 1, lane, c);
+  };
+
+  /* jb = -1 is the prologue P(0); one call site of the (large, fully unrolled) potrf32 body */
+  for (int jb = -1; jb < 3; jb++) {
+    if (jb >= 0) {
+    /* T(jb): rows below, X = B Dinv^T on MFMA, one 16-row strip (both column fragments) per unit; Dinv is
+       lower triangular, so the first 16 columns need K = 16 only.  Strips 0, 1 (block (jb+1, jb)) are on the chain. */
     for (int u = wave; u < (3 - jb) * 2; u += 4) {
       double *Bb = S + pblk(jb + 1 + (u >> 1), jb);
       const int fi = u & 1;
@@ -336,20 +351,25 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
     }
     __syncthreads();
     TSTAMP(4 + jb * 4);
-    /* trailing update: blk(bi,bj) -= blk(bi,jb) blk(bj,jb)^T for jb < bj <= bi */
-    const int nt = 3 - jb, npairs = nt * (nt + 1) / 2;
-    for (int u = wave; u < npairs * 4; u += 4) {
-      const int pr = u >> 2, f = u & 3;
-      int ri = 0;
-      while ((ri + 1) * (ri + 2) / 2 <= pr) ri++;
-      const int rj = pr - ri * (ri + 1) / 2;
-      const int bi = jb + 1 + ri, bj = jb + 1 + rj;
-      double *Cb = S + pblk(bi, bj);
-      double4_t c = frag_load(Cb, f >> 1, f & 1, lane);
-      c = frag_nt(S + pblk(bi, jb), S + pblk(bj, jb), f >> 1, f & 1, lane, c, -1.0);
-      frag_store(Cb, f >> 1, f & 1, lane, c);
+    /* U1(jb): the next diagonal block, lower fragments (0,0), (1,0), (1,1) on waves 0..2 */
+    if (wave < 3) update_frag(jb, jb + 1, jb + 1, wave == 0 ? 0 : wave + 1);
+    __syncthreads();
+    TSTAMP(5 + jb * 4);
     }
-    if (nt) __syncthreads();
+    /* P(jb+1) on wave 0  ||  U2(jb) on waves 1..3 */
+    if (wave == 0) {
+      potrf_block(jb + 1);
+    } else if (jb >= 0) {
+      int unit = 0;
+      for (int bi = jb + 2; bi < 4; bi++)
+        for (int bj = jb + 1; bj <= bi; bj++)
+          for (int f = 0; f < 4; f++) {
+            if (bi == bj && f == 1) continue;           /* strictly upper fragment of a diagonal block: never read */
+            if (unit++ % 3 == wave - 1) update_frag(jb, bi, bj, f);
+          }
+    }
+    __syncthreads();
+    TSTAMP(6 + jb * 4);
   }
 
   TSTAMP(18);

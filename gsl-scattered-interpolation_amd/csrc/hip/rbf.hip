@@ -493,7 +493,11 @@ extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, doub
   /* few targets: 1 per lane keeps more CUs busy; many: 2 per lane for ILP */
   const bool small = m < (size_t)EV_THREADS * 2 * 512;
   static const bool no_cull = getenv("GSL_SINTERP_NO_CULL") && getenv("GSL_SINTERP_NO_CULL")[0] == '1';
-  if (kind == GSL_SINTERP_RBF_GAUSSIAN && d_perm && !no_cull && n >= 1024 && (n + CT - 1) / CT <= CULL_MAX_TILES)
+  /* The culled kernel sums in the Morton order of the centres, the plain one in input order.  Which of the two
+     runs must not depend on the batch (a target's value is a function of the model and the target alone, so a
+     batch split into shards -- or a single-point call -- returns the bits of the one-batch result): it is chosen
+     by N only; small batches simply run the culled kernel without the target sort. */
+  if (kind == GSL_SINTERP_RBF_GAUSSIAN && !no_cull && n >= 1024 && (n + CT - 1) / CT <= CULL_MAX_TILES)
     return small ? launch_eval_cull<1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
                  : launch_eval_cull<2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
   if (kind == GSL_SINTERP_RBF_GAUSSIAN)

@@ -14,9 +14,11 @@ lib = pkg.capi.lib()
 out = (ctypes.c_ulonglong * 80)()
 lib.gsl_sinterp_hip_debug_diag_ts(out)
 t = np.array(list(out), dtype=np.int64)
-names = {0:'start',1:'loaded',18:'factored',19:'end'}
-for jb in range(4):
-    names[2+jb*4]='jb%d begin'%jb; names[3+jb*4]='jb%d potrf done'%jb; names[4+jb*4]='jb%d trsm done'%jb
+names = {0: 'start', 1: 'loaded', 2: 'P(0) done', 18: 'factored', 19: 'end'}
+for jb in range(3):
+    names[4 + jb * 4] = 'T(%d) done' % jb
+    names[5 + jb * 4] = 'U1(%d) done' % jb
+    names[6 + jb * 4] = 'P(%d) || U2(%d) done' % (jb + 1, jb)
 prev = t[0]
 for i in sorted(names):
     print('%-16s %8d ticks  (+%d)' % (names[i], t[i]-t[0], t[i]-prev)); prev = t[i]
