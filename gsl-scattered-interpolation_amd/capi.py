@@ -125,6 +125,7 @@ SIGNATURES = {
     "gsl_sinterp_hip_rbf_eval": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp]),
     "gsl_sinterp_hip_rbf_solve": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _pi]),
     "gsl_sinterp_hip_gemm_minus": (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _vp, _sz, _i, _vp, _sz, _i]),
+    "gsl_sinterp_hip_grid_targets": (_i, [_vp, _d, _d, _sz, _d, _d, _sz, _vp]),
     "gsl_sinterp_hip_synth_unit": (_i, [_vp, C.c_uint64, C.c_uint64, _d, _d, _vp, _sz]),
     # device groups (multi-GPU target shards)
     "gsl_sinterp_hip_group_create": (_i, [C.POINTER(_vp), _pi, _i]),
@@ -166,6 +167,11 @@ SIGNATURES = {
     "simplex_tree_device_eval_many": (_i, [_vp, _pm, _pv, _pi]),
     "simplex_tree_device_eval_resident": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "simplex_tree_device_ctx": (_vp, [_vp]),
+    "check_leaf_nodes": (None, [_pt, _vp]),
+    "check_delaunay": (_i, [_pt, _pm]),
+    "output_triangulation": (None, [_pt, _pm, _pv, _i, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "simplex_tree_fwrite": (_i, [_vp, _pt]),
+    "simplex_tree_fread": (_pt, [_vp]),
     "simplex_tree_check_device": (_i, [_pt, _pm, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "simplex_tree_device_alloc_multi": (_vp, [_pt, _pm, _pi, _i]),
     "simplex_tree_device_n_devices": (_i, [_vp]),
@@ -185,6 +191,10 @@ SIGNATURES = {
     "gsl_sinterp_eval": (_d, [C.POINTER(gsl_sinterp), _pv]),
     "gsl_sinterp_eval_many": (_i, [C.POINTER(gsl_sinterp), _pm, _pv, _pi]),
     "gsl_sinterp_eval_resident": (_i, [C.POINTER(gsl_sinterp), _vp, _sz, _sz, _vp, _vp]),
+    "gsl_sinterp_eval_grid": (_i, [C.POINTER(gsl_sinterp), _pv, _pv, _pm]),
+    "gsl_sinterp_fprintf_grid": (_i, [_vp, _pv, _pv, _pm]),
+    "gsl_sinterp_fwrite": (_i, [_vp, C.POINTER(gsl_sinterp)]),
+    "gsl_sinterp_fread": (_i, [_vp, C.POINTER(gsl_sinterp)]),
     "gsl_sinterp_get_weights": (_i, [C.POINTER(gsl_sinterp), _pv]),
     "gsl_sinterp_free": (None, [C.POINTER(gsl_sinterp)]),
     # --- compat slice used by the bindings
@@ -209,6 +219,29 @@ def _declare(L):
 def _ptr(symbol):
     """value of an exported `const T *symbol` variable"""
     return C.c_void_p.in_dll(lib(), symbol).value
+
+
+# ------------------------------------------------------------------ C stdio (FILE * arguments)
+_libc = C.CDLL(None)
+_libc.fopen.restype = C.c_void_p
+_libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+_libc.fclose.argtypes = [C.c_void_p]
+
+
+class CFile:
+    """`with CFile(path, "wb") as fp:` -> a FILE * for the library's fwrite / fread / fprintf entries."""
+
+    def __init__(self, path, mode):
+        self.fp = _libc.fopen(str(path).encode(), mode.encode())
+        if not self.fp:
+            raise OSError(f"fopen({path!r}, {mode!r}) failed")
+
+    def __enter__(self):
+        return C.c_void_p(self.fp)
+
+    def __exit__(self, *exc):
+        _libc.fclose(C.c_void_p(self.fp))
+        self.fp = None
 
 
 # ------------------------------------------------------------------ views
@@ -450,6 +483,36 @@ class SimplexTree:
             raise GslError(GSL_EFAILED, "simplex_tree_device_alloc")
         return DeviceTree(h)
 
+    def fwrite(self, path):
+        with CFile(path, "wb") as fp:
+            return lib().simplex_tree_fwrite(fp, self._t)
+
+    @classmethod
+    def fread(cls, path, data=None):
+        with CFile(path, "rb") as fp:
+            t = lib().simplex_tree_fread(fp)
+        if not t:
+            return None
+        self = cls.__new__(cls)
+        self._t, self.data, self._mat = t, None, None
+        if data is not None:
+            self.set_data(data)
+        return self
+
+    def output_triangulation(self, response, standardize, lines=None, points=None, circles=None):
+        enc = lambda p: str(p).encode() if p is not None else None
+        r = as_vector(response) if response is not None else None
+        lib().output_triangulation(self._t, self._m(), C.byref(r) if r is not None else None, int(standardize),
+                                   enc(lines), enc(points), enc(circles))
+
+    def leaf_walk_order(self):
+        """node ids in the order check_leaf_nodes visits them"""
+        order = []
+        CB = C.CFUNCTYPE(None, _pt, C.c_int)
+        cb = CB(lambda tree, node: order.append(node))
+        lib().check_leaf_nodes(self._t, C.cast(cb, C.c_void_p))
+        return order
+
     def check_device(self, device=0):
         """(verdict, leaf_violations, delaunay_violations): check_leaf_nodes + check_delaunay on the GPU."""
         lv, dv = C.c_longlong(0), C.c_longlong(0)
@@ -562,6 +625,21 @@ class Sinterp:
 
     def eval_resident(self, d_y, m, ytda, d_s, d_leaf=None):
         return lib().gsl_sinterp_eval_resident(self._p, d_y, m, ytda, d_s, d_leaf)
+
+    def eval_grid(self, vmin, vmax, n0, n1):
+        grid = np.empty((n0, n1), dtype=np.float64)
+        st = lib().gsl_sinterp_eval_grid(self._p, C.byref(as_vector(np.ascontiguousarray(vmin, dtype=np.float64))),
+                                         C.byref(as_vector(np.ascontiguousarray(vmax, dtype=np.float64))),
+                                         C.byref(as_matrix(grid)))
+        return st, grid
+
+    def fwrite(self, path):
+        with CFile(path, "wb") as fp:
+            return lib().gsl_sinterp_fwrite(fp, self._p)
+
+    def fread(self, path):
+        with CFile(path, "rb") as fp:
+            return lib().gsl_sinterp_fread(fp, self._p)
 
     def weights(self):
         w = np.empty(self._p.contents.size, dtype=np.float64)

@@ -379,10 +379,16 @@ __device__ __forceinline__ void decode_tile(const GemmArgs &g, unsigned tile, in
       64x64  / 32x32, 4 waves,  48 KiB     -- updates with few 128-tiles (the K <= 512 levels of the
                                              recursions): 4x the workgroups, a 128-wide panel update
                                              is otherwise one 13.7 us tile per CU on a fraction of the CUs */
-template <int BM, int BN, int WM, int WN>
+/* SS consecutive 16-wide K sub-steps form one "group" = the unit between two barriers (and the unit of the
+   stream-K split); ST groups are resident in the LDS ring.  SS = 1, ST = 3 is the pipeline described above.
+   The small 64x64 tile spends only 0.43 us of MFMA work per 16-wide step -- less than a DMA round trip and
+   comparable to a barrier -- so it runs SS = 4, ST = 2 (128 KiB): a K = 128 update has its WHOLE operand
+   panel in flight from the first instruction and crosses two barriers instead of eight. */
+template <int BM, int BN, int WM, int WN, int SS = 1, int ST = DM_STAGES>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 1)
 gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 {
+  static_assert(ST == 3 || ST == 2, "ring depth");
   constexpr int WCOLS = BN / WN;                        /* waves along n */
   constexpr int NW = (BM / WM) * WCOLS;
   constexpr int NT = NW * 64;                           /* threads */
@@ -390,9 +396,12 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
   constexpr int A_TILE = BM * GT_BK, B_TILE = BN * GT_BK;
   constexpr int A_CH = BM / 8 / NW, B_CH = (BN / 8) / NW;
   static_assert(A_CH >= 1 && B_CH >= 1 && A_CH * 8 * NW == BM && B_CH * 8 * NW == BN, "tile / wave split");
+  constexpr int PER_GROUP = SS * (A_CH + B_CH);         /* DMA wave-instructions a wave issues per group */
+  static_assert(PER_GROUP <= 32, "vmcnt immediate");
+  constexpr size_t GK = (size_t)GT_BK * SS;             /* K extent of a group */
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *sA = smem;
-  double *sB = smem + DM_STAGES * A_TILE;
+  double *sB = smem + ST * SS * A_TILE;
 
   const unsigned G = gridDim.x, bid = blockIdx.x;
   const unsigned q = G / 8, r = G % 8, xcd = bid % 8;
@@ -444,11 +453,15 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
         const int rr = (wave * B_CH + i) * 8 + (lane >> 3);
         srcB[i] = g.B + (col0 + rr) * g.ldb + (((lane & 7) ^ ((rr >> 1) & 7)) << 1);
       }
+      /* one group = SS sub-steps, each its own [rows][16] swizzled image (slot = stage * SS + sub-step) */
       auto issue = [&](int stage, size_t k0) {
 #pragma unroll
-        for (int i = 0; i < A_CH; i++) dma16(srcA[i] + k0, sA + stage * A_TILE + (wave * A_CH + i) * 128);
+        for (int ss = 0; ss < SS; ss++) {
 #pragma unroll
-        for (int i = 0; i < B_CH; i++) dma16(srcB[i] + k0, sB + stage * B_TILE + (wave * B_CH + i) * 128);
+          for (int i = 0; i < A_CH; i++) dma16(srcA[i] + k0 + ss * GT_BK, sA + (stage * SS + ss) * A_TILE + (wave * A_CH + i) * 128);
+#pragma unroll
+          for (int i = 0; i < B_CH; i++) dma16(srcB[i] + k0 + ss * GT_BK, sB + (stage * SS + ss) * B_TILE + (wave * B_CH + i) * 128);
+        }
       };
 
 #pragma unroll
@@ -457,32 +470,48 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
         for (int j = 0; j < FN; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
       __syncthreads();                                   /* the ring is free: previous segment fully read */
-      issue(0, (size_t)s0 * GT_BK);
-      if (s0 + 1 < s1) issue(1, (size_t)(s0 + 1) * GT_BK);
+      issue(0, (size_t)s0 * GK);
+      if (s0 + 1 < s1) issue(1, (size_t)(s0 + 1) * GK);
       for (unsigned s = s0; s < s1; s++) {
         const unsigned rel = s - s0;
+        /* group s has landed once at most the DMAs of group s+1 are still outstanding */
         if (s + 1 < s1) {
-          if constexpr (A_CH + B_CH == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else if constexpr (A_CH + B_CH == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          else { static_assert(A_CH + B_CH == 4 || A_CH + B_CH == 6 || A_CH + B_CH == 8, "vmcnt immediate"); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+          if constexpr (PER_GROUP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else if constexpr (PER_GROUP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else if constexpr (PER_GROUP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else { static_assert(PER_GROUP == 4 || PER_GROUP == 6 || PER_GROUP == 8 || PER_GROUP == 16, "vmcnt immediate"); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < s1) issue((int)((rel + 2) % DM_STAGES), (size_t)(s + 2) * GT_BK);
-        const double *a_base = sA + (rel % DM_STAGES) * A_TILE + arow;
-        const double *b_base = sB + (rel % DM_STAGES) * B_TILE + brow;
+        if constexpr (ST == 3) {
+          if (s + 2 < s1) issue((int)((rel + 2) % 3), (size_t)(s + 2) * GK);   /* ring slot read at step s-1 */
+        }
+        const int stage = (int)(rel % ST);
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          double af[FM], bf[FN];
+        for (int ss = 0; ss < SS; ss++) {
+          const double *a_base = sA + (stage * SS + ss) * A_TILE + arow;
+          const double *b_base = sB + (stage * SS + ss) * B_TILE + brow;
 #pragma unroll
-          for (int i = 0; i < FM; i++) af[i] = a_base[i * 16 * GT_BK + koff[kk]];
+          for (int kk = 0; kk < 4; kk++) {
+            double af[FM], bf[FN];
 #pragma unroll
-          for (int j = 0; j < FN; j++) bf[j] = b_base[j * 16 * GT_BK + koff[kk]];
+            for (int i = 0; i < FM; i++) af[i] = a_base[i * 16 * GT_BK + koff[kk]];
 #pragma unroll
-          for (int i = 0; i < FM; i++)
+            for (int j = 0; j < FN; j++) bf[j] = b_base[j * 16 * GT_BK + koff[kk]];
 #pragma unroll
-            for (int j = 0; j < FN; j++)
-              acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < FM; i++)
+#pragma unroll
+              for (int j = 0; j < FN; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+          }
+        }
+        if constexpr (ST == 2) {
+          /* two-deep ring: the stage just read is refilled with group s+2 once every wave has left it */
+          if (s + 2 < s1) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue(stage, (size_t)(s + 2) * GK);
+          }
         }
       }
     }
@@ -676,7 +705,7 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
     if (ctx->sk_wgs > 0 && !ctx->use_lookahead) {
       /* stream-K: G persistent workgroups share the (tile, K-step) space evenly */
       StreamK x;
-      x.steps = (unsigned)(k / GT_BK);
+      x.steps = (unsigned)(k / GT_BK);                   /* groups per tile; rescaled below for the grouped 64x64 variant */
       x.partial = ctx->d_sk_partial; x.flags = ctx->d_sk_flags;
       GemmArgs h = g;
       unsigned tiles = grid;
@@ -702,8 +731,11 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
         tiles = (unsigned)h.tiles_m * (unsigned)h.tiles_n;
         if (lower_only) { const unsigned tn_ = (unsigned)h.tiles_n; tiles = tn_ * (tn_ + 1) / 2 + ((unsigned)h.tiles_m - tn_) * tn_; }
       }
+      static const bool no_group = getenv("GSL_SINTERP_NO_GEMM_GROUP") && getenv("GSL_SINTERP_NO_GEMM_GROUP")[0] == '1';
+      const bool grouped = cfg == 2 && !no_group && (k % (4 * GT_BK)) == 0;
+      if (grouped) x.steps = (unsigned)(k / (4 * GT_BK));
       unsigned long long total64 = (unsigned long long)tiles * x.steps;
-      unsigned long long want = total64 / 16;            /* >= 16 K-steps per workgroup ... */
+      unsigned long long want = total64 / (grouped ? 4 : 16);   /* >= 16 K-steps (of 16) per workgroup ... */
       if (want < tiles) want = tiles;                     /* ... but never fewer workgroups than tiles */
       if (want > (unsigned long long)ctx->sk_wgs) want = (unsigned long long)ctx->sk_wgs;
       const unsigned G = (unsigned)(want ? want : 1);
@@ -721,6 +753,10 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
         const size_t lds = (size_t)DM_STAGES * (128 + 128) * GT_BK * sizeof(double);
         { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<128, 128, 64, 64>, (int)lds); if (ast) return ast; }
         hipLaunchKernelGGL((gemm_minus_streamk_kernel<128, 128, 64, 64>), dim3(G), dim3(256), lds, ctx->stream, h, x);
+      } else if (grouped) {
+        const size_t lds = (size_t)2 * 4 * (64 + 64) * GT_BK * sizeof(double);       /* 128 KiB */
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<64, 64, 32, 32, 4, 2>, (int)lds); if (ast) return ast; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<64, 64, 32, 32, 4, 2>), dim3(G), dim3(256), lds, ctx->stream, h, x);
       } else {
         const size_t lds = (size_t)DM_STAGES * (64 + 64) * GT_BK * sizeof(double);
         { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<64, 64, 32, 32>, (int)lds); if (ast) return ast; }

@@ -362,3 +362,35 @@ extern "C" int gsl_sinterp_hip_synth_unit(gsl_sinterp_hip_ctx *ctx, uint64_t see
   LAUNCH_CHECK(ctx);
   return ST_SUCCESS;
 }
+
+
+/* Targets of a regular n0 x n1 grid, generated in HBM: row (i * n1 + j) = (min0 + step0 * i, min1 + step1 * j) --
+   the loop of interpolation/scattered_interp_example.c:183-197 (x = min[0] + xstep * i, one multiply and one
+   add, separately rounded: this file is compiled with -ffp-contract=off), so the coordinates are the bits the
+   reference's host loop produces and nothing crosses PCIe on the way in. */
+__global__ void grid_targets_kernel(double min0, double step0, size_t n0, double min1, double step1, size_t n1,
+                                    double *__restrict__ y)
+{
+  const size_t total = n0 * n1, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+    const size_t i = k / n1, j = k - i * n1;
+    double2 v;
+    v.x = min0 + step0 * (double)i;
+    v.y = min1 + step1 * (double)j;
+    *reinterpret_cast<double2 *>(y + 2 * k) = v;
+  }
+}
+
+extern "C" int gsl_sinterp_hip_grid_targets(gsl_sinterp_hip_ctx *ctx, double min0, double step0, size_t n0, double min1,
+                                            double step1, size_t n1, double *d_y)
+{
+  REQUIRE(ctx, ctx != NULL && d_y != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  REQUIRE(ctx, (((uintptr_t)d_y) & 15) == 0, ST_EINVAL);
+  if (n0 == 0 || n1 == 0) return ST_SUCCESS;
+  size_t blocks = (n0 * n1 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(grid_targets_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, min0, step0, n0, min1, step1, n1, d_y);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}

@@ -548,9 +548,49 @@ static void rbf_free(void *vstate)
   free(st);
 }
 
+static int rbf_prepare_devices(gsl_sinterp *interp, rbf_state *st);
+
 static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *f)
 {
   rbf_state *st = (rbf_state *)interp->state;
+  const size_t n = st->n, dim = st->dim;
+  const int nd = interp->n_devices > 1 ? interp->n_devices : 1;
+  int s = rbf_prepare_devices(interp, st);
+  if (s) return s;
+  gsl_sinterp_hip_ctx *c = st->ctx;
+  st->eps = interp->shape > 0 ? interp->shape : 2.0 * pow((double)n, 1.0 / (double)dim);
+
+  double *h_x = (double *)malloc(n * dim * sizeof(double));
+  double *h_f = (double *)malloc(n * sizeof(double));
+  if (!h_x || !h_f) { free(h_x); free(h_f); GSL_ERROR("gsl_sinterp_init: out of memory", GSL_ENOMEM); }
+  for (size_t i = 0; i < n; i++) {
+    for (size_t cdim = 0; cdim < dim; cdim++) h_x[i * dim + cdim] = x->data[i * x->tda + cdim];
+    h_f[i] = gsl_vector_get(f, i);
+  }
+  const size_t model_bytes = n * (dim + 1) * sizeof(double);
+  double *d_phi = NULL;
+  int route = 0;
+  s = gsl_sinterp_hip_malloc(c, (void **)&d_phi, n * n * sizeof(double));
+  if (!s) s = gsl_sinterp_hip_h2d(c, st->d_x, h_x, n * dim * sizeof(double));
+  if (!s) s = gsl_sinterp_hip_h2d(c, st->d_w, h_f, n * sizeof(double));
+  /* fill + dense solve on the device: Cholesky (Gaussian), shifted-SPD Cholesky with a
+     Woodbury correction or pivoted LU (thin-plate spline) -- csrc/hip/solve.hip */
+  if (!s) s = gsl_sinterp_hip_rbf_solve(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, &route);
+  /* replicate the solved model: ONE broadcast of the weight vector (+ centres) */
+  if (!s && st->ss.grp) s = gsl_sinterp_hip_group_broadcast(st->ss.grp, (void *const *)st->m_model, model_bytes);
+  if (!s) s = gsl_sinterp_hip_sync(c);
+  if (st->ss.grp)
+    for (int r = 1; r < nd; r++) { int s2 = gsl_sinterp_hip_sync(gsl_sinterp_hip_group_ctx(st->ss.grp, r)); if (!s) s = s2; }
+  gsl_sinterp_hip_free(c, d_phi);
+  free(h_x); free(h_f);
+  if (s == GSL_EDOM) GSL_ERROR("gsl_sinterp_init: kernel matrix is not positive definite", GSL_EDOM);
+  HIP_TRY(s, c);
+  return GSL_SUCCESS;
+}
+
+/* contexts (one, or a device group) + the model buffer [centres | weights] of every member */
+static int rbf_prepare_devices(gsl_sinterp *interp, rbf_state *st)
+{
   const size_t n = st->n, dim = st->dim;
   const int nd = interp->n_devices > 1 ? interp->n_devices : 1;
   /* (re)build the device side when the requested device set changed */
@@ -569,16 +609,6 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
       GSL_ERROR("gsl_sinterp_init: no usable HIP device (GPU path has no CPU fallback)", GSL_EFAILED);
     }
   }
-  gsl_sinterp_hip_ctx *c = st->ctx;
-  st->eps = interp->shape > 0 ? interp->shape : 2.0 * pow((double)n, 1.0 / (double)dim);
-
-  double *h_x = (double *)malloc(n * dim * sizeof(double));
-  double *h_f = (double *)malloc(n * sizeof(double));
-  if (!h_x || !h_f) { free(h_x); free(h_f); GSL_ERROR("gsl_sinterp_init: out of memory", GSL_ENOMEM); }
-  for (size_t i = 0; i < n; i++) {
-    for (size_t cdim = 0; cdim < dim; cdim++) h_x[i * dim + cdim] = x->data[i * x->tda + cdim];
-    h_f[i] = gsl_vector_get(f, i);
-  }
   /* the model = [centres | weights], one buffer per member: N (d+1) 8 bytes, the broadcast payload */
   const size_t model_bytes = n * (dim + 1) * sizeof(double);
   int s = GSL_SUCCESS;
@@ -587,26 +617,10 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
       if (!st->m_model[r]) s = gsl_sinterp_hip_malloc(gsl_sinterp_hip_group_ctx(st->ss.grp, r), (void **)&st->m_model[r], model_bytes);
     st->d_x = st->m_model[0];
   } else if (!st->d_x) {
-    s = gsl_sinterp_hip_malloc(c, (void **)&st->d_x, model_bytes);
+    s = gsl_sinterp_hip_malloc(st->ctx, (void **)&st->d_x, model_bytes);
   }
   st->d_w = st->d_x ? st->d_x + n * dim : NULL;
-  double *d_phi = NULL;
-  int route = 0;
-  if (!s) s = gsl_sinterp_hip_malloc(c, (void **)&d_phi, n * n * sizeof(double));
-  if (!s) s = gsl_sinterp_hip_h2d(c, st->d_x, h_x, n * dim * sizeof(double));
-  if (!s) s = gsl_sinterp_hip_h2d(c, st->d_w, h_f, n * sizeof(double));
-  /* fill + dense solve on the device: Cholesky (Gaussian), shifted-SPD Cholesky with a
-     Woodbury correction or pivoted LU (thin-plate spline) -- csrc/hip/solve.hip */
-  if (!s) s = gsl_sinterp_hip_rbf_solve(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, &route);
-  /* replicate the solved model: ONE broadcast of the weight vector (+ centres) */
-  if (!s && st->ss.grp) s = gsl_sinterp_hip_group_broadcast(st->ss.grp, (void *const *)st->m_model, model_bytes);
-  if (!s) s = gsl_sinterp_hip_sync(c);
-  if (st->ss.grp)
-    for (int r = 1; r < nd; r++) { int s2 = gsl_sinterp_hip_sync(gsl_sinterp_hip_group_ctx(st->ss.grp, r)); if (!s) s = s2; }
-  gsl_sinterp_hip_free(c, d_phi);
-  free(h_x); free(h_f);
-  if (s == GSL_EDOM) GSL_ERROR("gsl_sinterp_init: kernel matrix is not positive definite", GSL_EDOM);
-  HIP_TRY(s, c);
+  if (s) { gsl_error(gsl_sinterp_hip_last_error(st->ctx), __FILE__, __LINE__, s); return s; }
   return GSL_SUCCESS;
 }
 
@@ -673,6 +687,7 @@ typedef struct {
   simplex_tree *tree;
   simplex_tree_device *dev;
   gsl_matrix *x; /* private copy of the centres: the tree keeps pointers into it */
+  gsl_vector *f; /* private copy of the response (checkpoints) */
 } simplex_state;
 
 static void *simplex_alloc(size_t dim, size_t size)
@@ -690,7 +705,18 @@ static void simplex_free(void *vstate)
   simplex_tree_device_free(st->dev);
   simplex_tree_free(st->tree);
   gsl_matrix_free(st->x);
+  gsl_vector_free(st->f);
   free(st);
+}
+
+/* mirror st->tree (built over st->x) on the interpolant's device(s) and bind st->f */
+static int simplex_mirror(gsl_sinterp *interp, simplex_state *st)
+{
+  simplex_tree_device_free(st->dev);
+  st->dev = interp->n_devices > 1 ? simplex_tree_device_alloc_multi(st->tree, st->x, interp->devices, interp->n_devices)
+                                  : simplex_tree_device_alloc(st->tree, st->x, interp->device);
+  if (!st->dev) return GSL_EFAILED;
+  return simplex_tree_device_set_response(st->dev, st->f);
 }
 
 static int simplex_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *f)
@@ -709,10 +735,11 @@ static int simplex_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vect
   if (!st->tree) return GSL_ENOMEM;
   int s = simplex_tree_init(st->tree, st->x, NULL, NULL, interp->init_flags, interp->rng);
   if (s != GSL_SUCCESS) return s;
-  st->dev = interp->n_devices > 1 ? simplex_tree_device_alloc_multi(st->tree, st->x, interp->devices, interp->n_devices)
-                                  : simplex_tree_device_alloc(st->tree, st->x, interp->device);
-  if (!st->dev) return GSL_EFAILED;
-  return simplex_tree_device_set_response(st->dev, f);
+  gsl_vector_free(st->f);
+  st->f = gsl_vector_alloc(st->n);
+  if (!st->f) return GSL_ENOMEM;
+  for (size_t i = 0; i < st->n; i++) gsl_vector_set(st->f, i, gsl_vector_get(f, i));
+  return simplex_mirror(interp, st);
 }
 
 static int simplex_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vector *s, int *leaf)
@@ -886,4 +913,169 @@ void gsl_sinterp_free(gsl_sinterp *interp)
   if (!interp) return;
   if (interp->type->free) interp->type->free(interp->state);
   free(interp);
+}
+
+/* ======================================================================== */
+/* gridded front-end (interpolation/scattered_interp_example.c:175-217)      */
+/* ======================================================================== */
+static gsl_sinterp_hip_ctx *interp_ctx0(const gsl_sinterp *interp)
+{
+  if (interp->type == &simplex_type) {
+    const simplex_state *st = (const simplex_state *)interp->state;
+    return st->dev ? st->dev->ctx : NULL;
+  }
+  return ((const rbf_state *)interp->state)->ctx;
+}
+
+int gsl_sinterp_eval_grid(const gsl_sinterp *interp, const gsl_vector *min, const gsl_vector *max, gsl_matrix *grid)
+{
+  if (!interp || !min || !max || !grid) GSL_ERROR("gsl_sinterp_eval_grid: null argument", GSL_EFAULT);
+  if (interp->dim != 2) GSL_ERROR("gsl_sinterp_eval_grid: 2-D interpolants only", GSL_EINVAL);
+  if (min->size != 2 || max->size != 2) GSL_ERROR("gsl_sinterp_eval_grid: min / max must have 2 components", GSL_EBADLEN);
+  gsl_sinterp_hip_ctx *c = interp_ctx0(interp);
+  if (!c) GSL_ERROR("gsl_sinterp_eval_grid: interpolant not initialised", GSL_EINVAL);
+  const size_t n0 = grid->size1, n1 = grid->size2, m = n0 * n1;
+  if (m == 0) return GSL_SUCCESS;
+  /* scattered_interp_example.c:179-183: step = range / n_grid */
+  const double min0 = gsl_vector_get(min, 0), min1 = gsl_vector_get(min, 1);
+  const double xrange = (gsl_vector_get(max, 0) - min0), xstep = xrange / (double)n0;
+  const double yrange = (gsl_vector_get(max, 1) - min1), ystep = yrange / (double)n1;
+  double *d_y = NULL, *d_s = NULL, *h_s = (double *)malloc(m * sizeof(double));
+  if (!h_s) GSL_ERROR("gsl_sinterp_eval_grid: out of memory", GSL_ENOMEM);
+  int st = gsl_sinterp_hip_malloc(c, (void **)&d_y, m * 2 * sizeof(double));
+  if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_s, m * sizeof(double));
+  if (!st) st = gsl_sinterp_hip_grid_targets(c, min0, xstep, n0, min1, ystep, n1, d_y);
+  int est = GSL_SUCCESS;
+  if (!st) {
+    gsl_error_handler_t *saved = gsl_set_error_handler_off();       /* EDOM (node outside the cage) is reported below */
+    est = interp->type->eval_resident(interp, d_y, m, 2, d_s, NULL);
+    gsl_set_error_handler(saved);
+    if (est != GSL_SUCCESS && est != GSL_EDOM) st = est;
+  }
+  if (!st) st = gsl_sinterp_hip_d2h(c, h_s, d_s, m * sizeof(double));
+  size_t n_nan = 0;
+  if (!st)
+    for (size_t i = 0; i < n0; i++)
+      for (size_t j = 0; j < n1; j++) { const double v = h_s[i * n1 + j]; n_nan += v != v; gsl_matrix_set(grid, i, j, v); }
+  gsl_sinterp_hip_free(c, d_y); gsl_sinterp_hip_free(c, d_s);
+  free(h_s);
+  HIP_TRY(st, c);
+  if (interp->type == &simplex_type && n_nan) GSL_ERROR("gsl_sinterp_eval_grid: grid node(s) outside the caging simplex", GSL_EDOM);
+  return GSL_SUCCESS;
+}
+
+int gsl_sinterp_fprintf_grid(FILE *stream, const gsl_vector *min, const gsl_vector *max, const gsl_matrix *grid)
+{
+  if (!stream || !min || !max || !grid) GSL_ERROR("gsl_sinterp_fprintf_grid: null argument", GSL_EFAULT);
+  if (min->size != 2 || max->size != 2) GSL_ERROR("gsl_sinterp_fprintf_grid: min / max must have 2 components", GSL_EBADLEN);
+  const size_t n0 = grid->size1, n1 = grid->size2;
+  const double min0 = gsl_vector_get(min, 0), min1 = gsl_vector_get(min, 1);
+  const double xstep = (gsl_vector_get(max, 0) - min0) / (double)n0, ystep = (gsl_vector_get(max, 1) - min1) / (double)n1;
+  for (size_t i = 0; i < n0; i++) {                                  /* scattered_interp_example.c:203-215 */
+    for (size_t j = 0; j < n1; j++)
+      if (fprintf(stream, "%g %g %g\n", min0 + xstep * (double)i, min1 + ystep * (double)j, gsl_matrix_get(grid, i, j)) < 0)
+        GSL_ERROR("fprintf failed", GSL_EFAILED);
+    if (fprintf(stream, "\n") < 0) GSL_ERROR("fprintf failed", GSL_EFAILED);
+  }
+  return GSL_SUCCESS;
+}
+
+/* ======================================================================== */
+/* binary checkpoint of an initialised interpolant                           */
+/*   magic "GSLSINT1" | type id | dim | size | eps | init_flags | payload    */
+/*   RBF payload: centres (size x dim) | weights (size)                      */
+/*   linear simplex payload: tree (simplex_tree_fwrite) | centres | response */
+/* ======================================================================== */
+static const char INTERP_MAGIC[8] = {'G', 'S', 'L', 'S', 'I', 'N', 'T', '1'};
+
+static int type_id(const gsl_sinterp_type *T) { return T == &gauss_type ? 0 : (T == &tps_type ? 1 : 2); }
+
+int gsl_sinterp_fwrite(FILE *stream, const gsl_sinterp *interp)
+{
+  if (!stream || !interp) GSL_ERROR("gsl_sinterp_fwrite: null argument", GSL_EFAULT);
+  const uint64_t head[3] = {(uint64_t)type_id(interp->type), (uint64_t)interp->dim, (uint64_t)interp->size};
+  if (interp->type == &simplex_type) {
+    const simplex_state *st = (const simplex_state *)interp->state;
+    if (!st->dev || !st->tree || !st->x || !st->f) GSL_ERROR("gsl_sinterp_fwrite: interpolant not initialised", GSL_EINVAL);
+    const double eps = 0.0;
+    const int64_t flags = interp->init_flags;
+    if (fwrite(INTERP_MAGIC, 1, 8, stream) != 8 || fwrite(head, sizeof head[0], 3, stream) != 3 ||
+        fwrite(&eps, sizeof eps, 1, stream) != 1 || fwrite(&flags, sizeof flags, 1, stream) != 1)
+      GSL_ERROR("fwrite failed", GSL_EFAILED);
+    int s = simplex_tree_fwrite(stream, st->tree);
+    if (s) return s;
+    for (size_t i = 0; i < st->n; i++) {
+      const double row[3] = {gsl_matrix_get(st->x, i, 0), gsl_matrix_get(st->x, i, 1), gsl_vector_get(st->f, i)};
+      if (fwrite(row, sizeof(double), 3, stream) != 3) GSL_ERROR("fwrite failed", GSL_EFAILED);
+    }
+    return GSL_SUCCESS;
+  }
+  const rbf_state *st = (const rbf_state *)interp->state;
+  if (!st->d_w) GSL_ERROR("gsl_sinterp_fwrite: interpolant not initialised", GSL_EINVAL);
+  const size_t cnt = st->n * (st->dim + 1);
+  double *h = (double *)malloc(cnt * sizeof(double));
+  if (!h) GSL_ERROR("gsl_sinterp_fwrite: out of memory", GSL_ENOMEM);
+  int s = gsl_sinterp_hip_d2h(st->ctx, h, st->d_x, cnt * sizeof(double));      /* the model buffer: [centres | weights] */
+  const int64_t flags = 0;
+  if (!s && (fwrite(INTERP_MAGIC, 1, 8, stream) != 8 || fwrite(head, sizeof head[0], 3, stream) != 3 ||
+             fwrite(&st->eps, sizeof st->eps, 1, stream) != 1 || fwrite(&flags, sizeof flags, 1, stream) != 1 ||
+             fwrite(h, sizeof(double), cnt, stream) != cnt)) {
+    free(h);
+    GSL_ERROR("fwrite failed", GSL_EFAILED);
+  }
+  free(h);
+  HIP_TRY(s, st->ctx);
+  return GSL_SUCCESS;
+}
+
+int gsl_sinterp_fread(FILE *stream, gsl_sinterp *interp)
+{
+  if (!stream || !interp) GSL_ERROR("gsl_sinterp_fread: null argument", GSL_EFAULT);
+  char magic[8];
+  uint64_t head[3];
+  double eps;
+  int64_t flags;
+  if (fread(magic, 1, 8, stream) != 8 || memcmp(magic, INTERP_MAGIC, 8) != 0)
+    GSL_ERROR("gsl_sinterp_fread: not a gsl_sinterp checkpoint", GSL_EFAILED);
+  if (fread(head, sizeof head[0], 3, stream) != 3 || fread(&eps, sizeof eps, 1, stream) != 1 ||
+      fread(&flags, sizeof flags, 1, stream) != 1)
+    GSL_ERROR("fread failed", GSL_EFAILED);
+  if (head[0] != (uint64_t)type_id(interp->type) || head[1] != interp->dim || head[2] != interp->size)
+    GSL_ERROR("gsl_sinterp_fread: checkpoint does not match the type / dim / size of the interpolant", GSL_EBADLEN);
+  if (interp->type == &simplex_type) {
+    simplex_state *st = (simplex_state *)interp->state;
+    simplex_tree *tree = simplex_tree_fread(stream);
+    if (!tree) return GSL_EFAILED;
+    if ((size_t)tree->n_points != st->n) { simplex_tree_free(tree); GSL_ERROR("gsl_sinterp_fread: tree / size mismatch", GSL_EBADLEN); }
+    gsl_matrix *x = gsl_matrix_alloc(st->n, 2);
+    gsl_vector *f = gsl_vector_alloc(st->n);
+    int ok = x && f;
+    for (size_t i = 0; ok && i < st->n; i++) {
+      double row[3];
+      ok = fread(row, sizeof(double), 3, stream) == 3;
+      if (ok) { gsl_matrix_set(x, i, 0, row[0]); gsl_matrix_set(x, i, 1, row[1]); gsl_vector_set(f, i, row[2]); }
+    }
+    if (!ok) { simplex_tree_free(tree); gsl_matrix_free(x); gsl_vector_free(f); GSL_ERROR("fread failed", GSL_EFAILED); }
+    simplex_tree_device_free(st->dev); st->dev = NULL;
+    simplex_tree_free(st->tree); gsl_matrix_free(st->x); gsl_vector_free(st->f);
+    st->tree = tree; st->x = x; st->f = f;
+    interp->init_flags = (int)flags;
+    return simplex_mirror(interp, st);                  /* upload + pack + bind: no triangulation */
+  }
+  rbf_state *st = (rbf_state *)interp->state;
+  const size_t cnt = st->n * (st->dim + 1);
+  double *h = (double *)malloc(cnt * sizeof(double));
+  if (!h) GSL_ERROR("gsl_sinterp_fread: out of memory", GSL_ENOMEM);
+  if (fread(h, sizeof(double), cnt, stream) != cnt) { free(h); GSL_ERROR("fread failed", GSL_EFAILED); }
+  int s = rbf_prepare_devices(interp, st);
+  if (s) { free(h); return s; }
+  st->eps = eps;
+  s = gsl_sinterp_hip_h2d(st->ctx, st->d_x, h, cnt * sizeof(double));
+  if (!s && st->ss.grp) s = gsl_sinterp_hip_group_broadcast(st->ss.grp, (void *const *)st->m_model, cnt * sizeof(double));
+  if (!s) s = gsl_sinterp_hip_sync(st->ctx);
+  if (st->ss.grp)
+    for (int r = 1; r < st->ss.n; r++) { int s2 = gsl_sinterp_hip_sync(gsl_sinterp_hip_group_ctx(st->ss.grp, r)); if (!s) s = s2; }
+  free(h);
+  HIP_TRY(s, st->ctx);
+  return GSL_SUCCESS;                                   /* nothing was filled, factorised or solved */
 }

@@ -27,6 +27,7 @@
 #include "gsl_sinterp_compat.h"
 #include "gsl_sinterp_hip.h"
 #include <assert.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -169,6 +170,18 @@ simplex_tree_device *simplex_tree_device_alloc_multi(simplex_tree *tree, gsl_mat
 int simplex_tree_device_n_devices(const simplex_tree_device *dev);
 const char *simplex_tree_device_transport(const simplex_tree_device *dev);   /* "rccl" | "peer-copy" | "none" */
 
+/* The reference's traversal / dump entries (interpolation/linear_simplex_integrity_check.h:11-21), same signatures:
+   check_leaf_nodes walks the leaf adjacency depth first from the first leaf and applies fn to every leaf (the
+   reference's order); check_delaunay returns 1 when the device-side checks pass; output_triangulation writes
+   the gnuplot files of :246-284 (any name may be NULL). */
+void check_leaf_nodes(simplex_tree *tree, void (*fn)(simplex_tree *, simplex_index));
+int check_delaunay(simplex_tree *tree, gsl_matrix *data);
+void output_triangulation(simplex_tree *tree, gsl_matrix *data, gsl_vector *response, int standardize_output,
+                          char lines_filename[], char points_filename[], char circles_filename[]);
+/* binary checkpoint of a built tree (native byte order; GSL_EFAILED on a short or corrupt stream) */
+int simplex_tree_fwrite(FILE *stream, const simplex_tree *tree);
+simplex_tree *simplex_tree_fread(FILE *stream);
+
 /* check_leaf_nodes + check_delaunay of the reference (interpolation/linear_simplex_integrity_check.c:121-168;
    there an O(N^3) debug pass after every insertion) as two GPU kernels over the finished tree: O(leaves) and
    O(leaves x N).  Returns 1 when every predicate holds -- check_delaunay's own return convention (:162-168) --
@@ -230,6 +243,19 @@ double gsl_sinterp_eval(const gsl_sinterp *interp, const gsl_vector *y);
 int gsl_sinterp_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vector *s, int *leaf);
 int gsl_sinterp_eval_resident(const gsl_sinterp *interp, const double *d_y, size_t m, size_t ytda,
                               double *d_s, int *d_leaf);
+/* Gridded front-end (interpolation/scattered_interp_example.c:175-217): evaluate on the regular grid
+   x_i = min[0] + i (max[0]-min[0])/n0, y_j = min[1] + j (max[1]-min[1])/n1 (the reference's steps: range / n_grid,
+   the upper bounds excluded) with n0 = grid->size1, n1 = grid->size2; grid(i, j) receives the value.  The
+   targets are generated on the device; dim = 2 interpolants only.  gsl_sinterp_fprintf_grid writes the grid in
+   the reference's /tmp/plot.dat form ("%g %g %g" per node, a blank line after each i). */
+int gsl_sinterp_eval_grid(const gsl_sinterp *interp, const gsl_vector *min, const gsl_vector *max, gsl_matrix *grid);
+int gsl_sinterp_fprintf_grid(FILE *stream, const gsl_vector *min, const gsl_vector *max, const gsl_matrix *grid);
+/* Binary checkpoint of an INITIALISED interpolant (RBF: centres + solved weights; linear simplex: the built
+   history DAG + data + response), gsl_matrix_fwrite / _fread conventions (native byte order, GSL_EFAILED on a
+   short transfer).  fread needs an interpolant allocated with the same type, dim and size (GSL_EBADLEN
+   otherwise) and leaves it ready to evaluate: nothing is solved or triangulated again. */
+int gsl_sinterp_fwrite(FILE *stream, const gsl_sinterp *interp);
+int gsl_sinterp_fread(FILE *stream, gsl_sinterp *interp);
 /* RBF types: copy the solved weights (length size) to the host. */
 int gsl_sinterp_get_weights(const gsl_sinterp *interp, gsl_vector *w);
 void gsl_sinterp_free(gsl_sinterp *interp);

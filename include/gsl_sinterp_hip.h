@@ -156,6 +156,12 @@ int gsl_sinterp_hip_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, siz
                                size_t lda, const double *d_b, size_t ldb, int b_is_kn, double *d_c,
                                size_t ldc, int lower_only);
 
+/* ---- gridded front-end: the targets of an n0 x n1 grid generated in HBM ---- */
+/* row (i*n1 + j) of d_y (packed M x 2) = (min0 + step0*i, min1 + step1*j): the loop of
+   interpolation/scattered_interp_example.c:183-197, same operations, so the same bits */
+int gsl_sinterp_hip_grid_targets(gsl_sinterp_hip_ctx *ctx, double min0, double step0, size_t n0, double min1,
+                                 double step1, size_t n1, double *d_y);
+
 /* ---- synthetic clouds generated in HBM (bench / tests) ------- */
 int gsl_sinterp_hip_synth_unit(gsl_sinterp_hip_ctx *ctx, uint64_t seed, uint64_t first,
                                double offset, double span, double *d_out, size_t count);

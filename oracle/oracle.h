@@ -111,6 +111,11 @@ int oracle_bary_eval_many(oracle_tree *t, const double *data, size_t tda,
 int oracle_check_leaf_nodes(oracle_tree *t);
 int oracle_check_delaunay(oracle_tree *t, const double *data, size_t tda);
 uint64_t oracle_tree_hash(const oracle_tree *t);   /* FNV-1a over type/pidx/links */
+/* the gnuplot dumps of linear_simplex_integrity_check.c:170-284, written by the reference's RECURSIVE walk over the
+   leaf adjacency (:62-119: pre-order, neighbours by link index); any of the three file names may be NULL */
+int oracle_output_triangulation(oracle_tree *t, const double *data, size_t tda, const double *response, size_t rstride,
+                                int standardize_output, const char *lines_filename, const char *points_filename,
+                                const char *circles_filename);
 
 /* ======================= RBF harness (oracle_rbf.c) ================== */
 #define ORACLE_RBF_GAUSSIAN 0   /* phi = exp(-(eps r)^2)                    */

@@ -19,6 +19,7 @@
  * [k*(dim+1), (k+1)*(dim+1)) of both arrays; that identity is used directly.
  */
 #include "oracle.h"
+#include <stdio.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -628,6 +629,71 @@ int oracle_check_delaunay(oracle_tree *t, const double *data, size_t tda)
     }
   }
   return 1;
+}
+
+/* linear_simplex_integrity_check.c:170-284 */
+struct dump_ctx { FILE *flines, *fcircles; const double *data; size_t tda; const double *response; size_t rstride; int std_out; unsigned char *seen; };
+
+static void dump_leaf(oracle_tree *t, int node, struct dump_ctx *c)
+{
+  const int dim = t->dim;
+  if (c->flines)
+    for (int i = 0; i < dim + 1; i++)
+      for (int j = i + 1; j < dim + 1; j++) {
+        const int id[2] = {PT(t, node, i), PT(t, node, j)};
+        if (id[0] < 0 || id[1] < 0) continue;
+        for (int e = 0; e < 2; e++) {
+          const double *p = vertex(t, c->data, c->tda, id[e]);
+          const double r = c->response ? c->response[t->shuffle[id[e]] * c->rstride] : 0;
+          for (int k = 0; k < dim; k++)
+            fprintf(c->flines, "%g ", c->std_out ? t->scale[k] * (p[k] - t->shift[k]) : p[k]);
+          fprintf(c->flines, e == 0 ? "%g\n" : "%g\n\n\n", r);
+        }
+      }
+  if (c->fcircles) {
+    double x0[16] = {0}, r2 = 0;
+    int pts[17];
+    for (int i = 0; i < dim + 1; i++) pts[i] = PT(t, node, i);
+    (void)hypersphere_points(t, pts, c->data, c->tda, x0, &r2);
+    fprintf(c->fcircles, "%g %g %g\n", x0[0], x0[1], sqrt(r2));
+  }
+}
+
+static void dump_walk(oracle_tree *t, int node, struct dump_ctx *c)      /* :62-119, recursive like the reference */
+{
+  c->seen[node] = 1;
+  dump_leaf(t, node, c);
+  for (int i = 0; i < t->dim + 1; i++) {
+    const int nb = LK(t, node, i);
+    if (nb && !c->seen[nb]) dump_walk(t, nb, c);
+  }
+}
+
+int oracle_output_triangulation(oracle_tree *t, const double *data, size_t tda, const double *response, size_t rstride,
+                                int standardize_output, const char *lines_filename, const char *points_filename,
+                                const char *circles_filename)
+{
+  struct dump_ctx c = {NULL, NULL, data, tda, response, rstride, standardize_output, NULL};
+  if (lines_filename) c.flines = fopen(lines_filename, "w");
+  if (circles_filename) c.fcircles = fopen(circles_filename, "w");
+  if (points_filename) {
+    FILE *fp = fopen(points_filename, "w");
+    if (fp) {
+      for (int i = 0; i < t->n_points; i++) {
+        const double *q = data + t->shuffle[i] * tda;
+        fprintf(fp, "%g %g\n", t->scale[0] * (q[0] - t->shift[0]), t->scale[1] * (q[1] - t->shift[1]));
+      }
+      fclose(fp);
+    }
+  }
+  int leaf = 0;
+  while (!IS_LEAF(t, leaf)) leaf = LK(t, leaf, 0);                    /* :124-128 */
+  c.seen = (unsigned char *)calloc((size_t)t->n_nodes, 1);
+  if (c.seen) dump_walk(t, leaf, &c);
+  free(c.seen);
+  if (c.flines) fclose(c.flines);
+  if (c.fcircles) fclose(c.fcircles);
+  return ORACLE_SUCCESS;
 }
 
 uint64_t oracle_tree_hash(const oracle_tree *t)

@@ -133,6 +133,12 @@ class Tree:
     def check_delaunay(self, data):
         return lib().oracle_check_delaunay(self.t, _p(data), _sz(data.strides[0] // 8))
 
+    def output_triangulation(self, data, response, standardize, lines=None, points=None, circles=None):
+        enc = lambda p: str(p).encode() if p is not None else None
+        rs = response.strides[0] // 8 if response is not None else 1
+        return lib().oracle_output_triangulation(self.t, _p(data), _sz(data.strides[0] // 8), _p(response), _sz(rs),
+                                                 int(standardize), enc(lines), enc(points), enc(circles))
+
     def hash(self):
         return lib().oracle_tree_hash(self.t)
 
