@@ -33,8 +33,8 @@ def test_eval_grid_reproduces_the_example_sweep(pkg, orc, weather, tmp_path):
     nodes = np.array([[EX_MIN[0] + xstep * i, EX_MIN[1] + ystep * j] for i in range(n_grid) for j in range(n_grid)])
     want, _ = o.eval_many(data, resp, nodes)
     assert np.array_equal(bits(grid.reshape(-1)), bits(want))
-    # the survey-captured value at (-88, 41) lies on no grid node; the nearest nodes bracket it
-    assert 270.0 < grid.min() and grid.max() < 290.0
+    # inside the hull the interpolant is bounded by the data; outside it extrapolates along the hull edges (quirk q6)
+    assert np.isfinite(grid).all() and resp.min() - 15.0 < grid.min() and grid.max() < resp.max() + 15.0
     # plot.dat text: "%g %g %g" per node, blank line per i (example.c:203-215)
     import ctypes as C
     path = tmp_path / "plot.dat"
