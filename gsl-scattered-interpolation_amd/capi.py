@@ -14,6 +14,7 @@ GSL_SUCCESS, GSL_FAILURE = 0, -1
 GSL_EDOM, GSL_EFAULT, GSL_EINVAL, GSL_EFAILED, GSL_ENOMEM = 1, 3, 4, 5, 8
 GSL_EBADLEN, GSL_ENOTSQR, GSL_EUNIMPL = 19, 20, 24
 RBF_GAUSSIAN, RBF_TPS = 0, 1
+SOLVER_DEFAULT, SOLVER_CHOLESKY2, SOLVER_PCHOLESKY, SOLVER_LU_REFINE = 0, 1, 2, 3
 TREE_DEFAULT, TREE_NOSTANDARDIZE, TREE_ISOSCALE = 0, 1, 2
 TREE_RECORD_BYTES, TREE_LEAFTAB_BYTES = 64, 32
 
@@ -90,7 +91,8 @@ class simplex_tree(C.Structure):
 class gsl_sinterp(C.Structure):
     _fields_ = [("type", C.c_void_p), ("dim", C.c_size_t), ("size", C.c_size_t), ("device", C.c_int),
                 ("shape", C.c_double), ("init_flags", C.c_int), ("rng", C.c_void_p), ("state", C.c_void_p),
-                ("n_devices", C.c_int), ("devices", C.c_int * 64)]
+                ("n_devices", C.c_int), ("devices", C.c_int * 64), ("solver", C.c_int), ("want_rcond", C.c_int),
+                ("rcond", C.c_double), ("route", C.c_int)]
 
 
 _vp, _i, _sz, _d = C.c_void_p, C.c_int, C.c_size_t, C.c_double
@@ -122,6 +124,13 @@ SIGNATURES = {
     "gsl_sinterp_hip_cholesky_svx": (_i, [_vp, _sz, _vp, _sz, _vp]),
     "gsl_sinterp_hip_lu_decomp": (_i, [_vp, _sz, _vp, _sz, _vp, _pi]),
     "gsl_sinterp_hip_lu_svx": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "gsl_sinterp_hip_cholesky_decomp2": (_i, [_vp, _sz, _vp, _sz, _vp, _pi]),
+    "gsl_sinterp_hip_cholesky_svx2": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "gsl_sinterp_hip_cholesky_rcond": (_i, [_vp, _sz, _vp, _sz, _pd]),
+    "gsl_sinterp_hip_lu_refine": (_i, [_vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "gsl_sinterp_hip_pcholesky_decomp": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "gsl_sinterp_hip_pcholesky_svx": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "gsl_sinterp_hip_rbf_solve_ex": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _i, _pd, _pi]),
     "gsl_sinterp_hip_rbf_eval": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp]),
     "gsl_sinterp_hip_rbf_solve": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _pi]),
     "gsl_sinterp_hip_gemm_minus": (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _vp, _sz, _i, _vp, _sz, _i]),
@@ -180,6 +189,10 @@ SIGNATURES = {
     "gsl_sinterp_alloc": (C.POINTER(gsl_sinterp), [_vp, _sz, _sz]),
     "gsl_sinterp_set_device": (_i, [C.POINTER(gsl_sinterp), _i]),
     "gsl_sinterp_set_shape": (_i, [C.POINTER(gsl_sinterp), _d]),
+    "gsl_sinterp_set_solver": (_i, [C.POINTER(gsl_sinterp), _i]),
+    "gsl_sinterp_set_rcond": (_i, [C.POINTER(gsl_sinterp), _i]),
+    "gsl_sinterp_rcond": (_i, [C.POINTER(gsl_sinterp), _pd]),
+    "gsl_sinterp_route": (_i, [C.POINTER(gsl_sinterp)]),
     "gsl_sinterp_set_devices": (_i, [C.POINTER(gsl_sinterp), _i]),
     "gsl_sinterp_set_device_list": (_i, [C.POINTER(gsl_sinterp), _pi, _i]),
     "gsl_sinterp_n_devices": (_i, [C.POINTER(gsl_sinterp)]),
@@ -357,6 +370,34 @@ class HipContext:
 
     def rbf_eval(self, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s):
         check(lib().gsl_sinterp_hip_rbf_eval(self._h, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s), self._h)
+
+    def cholesky_decomp2(self, n, d_a, lda, d_s):
+        info = C.c_int(0)
+        st = lib().gsl_sinterp_hip_cholesky_decomp2(self._h, n, d_a, lda, d_s, C.byref(info))
+        return st, info.value
+
+    def cholesky_svx2(self, n, d_llt, lda, d_s, d_x):
+        check(lib().gsl_sinterp_hip_cholesky_svx2(self._h, n, d_llt, lda, d_s, d_x), self._h)
+
+    def cholesky_rcond(self, n, d_llt, lda):
+        r = C.c_double(0)
+        check(lib().gsl_sinterp_hip_cholesky_rcond(self._h, n, d_llt, lda, C.byref(r)), self._h)
+        return r.value
+
+    def lu_refine(self, n, d_a, lda, d_lu, ldlu, d_perm, d_b, d_x, d_work):
+        return lib().gsl_sinterp_hip_lu_refine(self._h, n, d_a, lda, d_lu, ldlu, d_perm, d_b, d_x, d_work)
+
+    def pcholesky_decomp(self, n, d_a, lda, d_perm):
+        check(lib().gsl_sinterp_hip_pcholesky_decomp(self._h, n, d_a, lda, d_perm), self._h)
+
+    def pcholesky_svx(self, n, d_ldlt, lda, d_perm, d_x):
+        check(lib().gsl_sinterp_hip_pcholesky_svx(self._h, n, d_ldlt, lda, d_perm, d_x), self._h)
+
+    def rbf_solve_ex(self, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, solver, want_rcond=False):
+        route, rc = C.c_int(0), C.c_double(0)
+        st = lib().gsl_sinterp_hip_rbf_solve_ex(self._h, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, solver,
+                                                C.byref(rc) if want_rcond else None, C.byref(route))
+        return st, route.value, rc.value
 
     def rbf_solve(self, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w):
         route = C.c_int(0)
@@ -588,6 +629,20 @@ class Sinterp:
 
     def set_shape(self, eps):
         return lib().gsl_sinterp_set_shape(self._p, eps)
+
+    def set_solver(self, solver):
+        return lib().gsl_sinterp_set_solver(self._p, solver)
+
+    def set_rcond(self, want=True):
+        return lib().gsl_sinterp_set_rcond(self._p, int(want))
+
+    def rcond(self):
+        r = C.c_double(0)
+        st = lib().gsl_sinterp_rcond(self._p, C.byref(r))
+        return st, r.value
+
+    def route(self):
+        return lib().gsl_sinterp_route(self._p)
 
     def set_devices(self, n):
         return lib().gsl_sinterp_set_devices(self._p, n)

@@ -227,3 +227,72 @@ extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, dou
   if (h_route) *h_route = 3;
   return gsl_sinterp_hip_lu_svx(ctx, n, d_phi, lda, d_perm, d_w);
 }
+
+
+/* explicit solver choice + optional condition estimate (include/gsl_sinterp_hip.h) */
+extern "C" int gsl_sinterp_hip_rbf_solve_ex(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim,
+                                            size_t xtda, double *d_phi, size_t lda, double *d_w, int solver, double *h_rcond,
+                                            int *h_route)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  EXCLUSIVE_SECTION(ctx);
+  REQUIRE(ctx, solver >= GSL_SINTERP_SOLVER_DEFAULT && solver <= GSL_SINTERP_SOLVER_LU_REFINE, ST_EINVAL);
+  if (h_rcond) *h_rcond = NAN;
+  if (h_route) *h_route = 0;
+  if (solver == GSL_SINTERP_SOLVER_DEFAULT) {
+    if (!h_rcond || kind != GSL_SINTERP_RBF_GAUSSIAN)
+      return gsl_sinterp_hip_rbf_solve(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, h_route);
+    int route = 0;
+    int st = gsl_sinterp_hip_rbf_solve(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, &route);
+    if (h_route) *h_route = route;
+    if (st || route != 1) return st;
+    return gsl_sinterp_hip_cholesky_rcond(ctx, n, d_phi, lda, h_rcond);     /* d_phi holds L + the original above the diagonal */
+  }
+  REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && lda >= n, ST_EINVAL);
+  REQUIRE(ctx, n == 0 || (d_x && d_phi && d_w), ST_EFAULT);
+  if (n == 0) return ST_SUCCESS;
+  int st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);
+  if (st) return st;
+  if (solver == GSL_SINTERP_SOLVER_CHOLESKY2) {
+    void *aux = NULL;
+    st = sinterp_aux(ctx, n * sizeof(double), &aux);
+    if (st) return st;
+    int info = 0;
+    st = gsl_sinterp_hip_cholesky_decomp2(ctx, n, d_phi, lda, (double *)aux, &info);
+    if (st) return st;
+    if (h_route) *h_route = 4;
+    if (h_rcond) { st = gsl_sinterp_hip_cholesky_rcond(ctx, n, d_phi, lda, h_rcond); if (st) return st; }
+    return gsl_sinterp_hip_cholesky_svx2(ctx, n, d_phi, lda, (const double *)aux, d_w);
+  }
+  if (solver == GSL_SINTERP_SOLVER_PCHOLESKY) {
+    int *d_perm = NULL;
+    st = gsl_sinterp_hip_malloc(ctx, (void **)&d_perm, n * sizeof(int));
+    if (!st) st = gsl_sinterp_hip_pcholesky_decomp(ctx, n, d_phi, lda, d_perm);
+    if (!st) st = gsl_sinterp_hip_pcholesky_svx(ctx, n, d_phi, lda, d_perm, d_w);
+    if (!st) st = gsl_sinterp_hip_sync(ctx);
+    gsl_sinterp_hip_free(ctx, d_perm);
+    if (!st && h_route) *h_route = 5;
+    return st;
+  }
+  /* LU + one refinement step: A (copy), LU (in d_phi), b (copy of the right-hand side) */
+  double *d_copy = NULL, *d_b = NULL, *d_work = NULL;
+  int *d_perm = NULL, signum = 0;
+  st = gsl_sinterp_hip_malloc(ctx, (void **)&d_copy, n * n * sizeof(double));
+  if (!st) st = gsl_sinterp_hip_malloc(ctx, (void **)&d_b, 2 * n * sizeof(double));
+  if (!st) st = gsl_sinterp_hip_malloc(ctx, (void **)&d_perm, n * sizeof(int));
+  if (!st) {
+    d_work = d_b + n;
+    hipError_t e = hipMemcpy2DAsync(d_copy, n * sizeof(double), d_phi, lda * sizeof(double), n * sizeof(double), n,
+                                    hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_b, d_w, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) st = sinterp_fail(ctx, ST_EFAILED, "rbf_solve_ex: copies", e, __FILE__, __LINE__);
+  }
+  if (!st) st = gsl_sinterp_hip_lu_decomp(ctx, n, d_phi, lda, d_perm, &signum);
+  if (!st) st = gsl_sinterp_hip_lu_svx(ctx, n, d_phi, lda, d_perm, d_w);
+  if (!st) st = gsl_sinterp_hip_lu_refine(ctx, n, d_copy, n, d_phi, lda, d_perm, d_b, d_w, d_work);
+  if (!st) st = gsl_sinterp_hip_sync(ctx);
+  gsl_sinterp_hip_free(ctx, d_copy); gsl_sinterp_hip_free(ctx, d_b); gsl_sinterp_hip_free(ctx, d_perm);
+  if (!st && h_route) *h_route = 6;
+  return st;
+}

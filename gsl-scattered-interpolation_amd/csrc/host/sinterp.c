@@ -575,7 +575,10 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
   if (!s) s = gsl_sinterp_hip_h2d(c, st->d_w, h_f, n * sizeof(double));
   /* fill + dense solve on the device: Cholesky (Gaussian), shifted-SPD Cholesky with a
      Woodbury correction or pivoted LU (thin-plate spline) -- csrc/hip/solve.hip */
-  if (!s) s = gsl_sinterp_hip_rbf_solve(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, &route);
+  double rcond = GSL_NAN;
+  if (!s) s = gsl_sinterp_hip_rbf_solve_ex(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, interp->solver,
+                                           interp->want_rcond ? &rcond : NULL, &route);
+  interp->rcond = rcond; interp->route = route;
   /* replicate the solved model: ONE broadcast of the weight vector (+ centres) */
   if (!s && st->ss.grp) s = gsl_sinterp_hip_group_broadcast(st->ss.grp, (void *const *)st->m_model, model_bytes);
   if (!s) s = gsl_sinterp_hip_sync(c);
@@ -783,6 +786,7 @@ gsl_sinterp *gsl_sinterp_alloc(const gsl_sinterp_type *T, size_t dim, size_t siz
   if (interp->n_devices >= 1) interp->device = interp->devices[0];
   else { interp->n_devices = 1; interp->devices[0] = interp->device; }
   interp->shape = 0.0; interp->init_flags = SIMPLEX_TREE_DEFAULT; interp->rng = NULL;
+  interp->solver = GSL_SINTERP_SOLVER_DEFAULT; interp->want_rcond = 0; interp->rcond = GSL_NAN; interp->route = 0;
   interp->state = T->alloc(dim, size);
   if (!interp->state) {
     free(interp);
@@ -831,6 +835,35 @@ int gsl_sinterp_set_shape(gsl_sinterp *interp, double eps)
   interp->shape = eps;
   return GSL_SUCCESS;
 }
+
+int gsl_sinterp_set_solver(gsl_sinterp *interp, int solver)
+{
+  if (!interp) GSL_ERROR("gsl_sinterp_set_solver: null interpolant", GSL_EFAULT);
+  if (solver < GSL_SINTERP_SOLVER_DEFAULT || solver > GSL_SINTERP_SOLVER_LU_REFINE)
+    GSL_ERROR("gsl_sinterp_set_solver: unknown solver", GSL_EINVAL);
+  if (interp->type == &simplex_type) GSL_ERROR("gsl_sinterp_set_solver: not an RBF interpolant", GSL_EINVAL);
+  if (interp->type == &tps_type && (solver == GSL_SINTERP_SOLVER_CHOLESKY2 || solver == GSL_SINTERP_SOLVER_PCHOLESKY))
+    GSL_ERROR("gsl_sinterp_set_solver: the thin-plate-spline matrix is indefinite (zero diagonal): no Cholesky-type solver", GSL_EINVAL);
+  interp->solver = solver;
+  return GSL_SUCCESS;
+}
+
+int gsl_sinterp_set_rcond(gsl_sinterp *interp, int want)
+{
+  if (!interp) GSL_ERROR("gsl_sinterp_set_rcond: null interpolant", GSL_EFAULT);
+  interp->want_rcond = want != 0;
+  return GSL_SUCCESS;
+}
+
+int gsl_sinterp_rcond(const gsl_sinterp *interp, double *rcond)
+{
+  if (!interp || !rcond) GSL_ERROR("gsl_sinterp_rcond: null argument", GSL_EFAULT);
+  *rcond = interp->rcond;
+  if (interp->rcond != interp->rcond) GSL_ERROR("gsl_sinterp_rcond: no estimate available (set_rcond + a Cholesky solver + init)", GSL_EINVAL);
+  return GSL_SUCCESS;
+}
+
+int gsl_sinterp_route(const gsl_sinterp *interp) { return interp ? interp->route : 0; }
 
 int gsl_sinterp_set_tree_options(gsl_sinterp *interp, int init_flags, gsl_rng *rng)
 {

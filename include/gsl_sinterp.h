@@ -218,6 +218,10 @@ struct gsl_sinterp_struct {
   void *state;
   int n_devices;     /* > 1: the model is replicated over devices[] and eval_many shards its targets */
   int devices[GSL_SINTERP_MAX_DEVICES];
+  int solver;        /* GSL_SINTERP_SOLVER_* (RBF types); default = by kernel class          */
+  int want_rcond;    /* estimate the reciprocal condition number at init (Cholesky solvers)  */
+  double rcond;      /* the estimate of the last init, NaN when none was made                */
+  int route;         /* solver route the last init took (gsl_sinterp_hip_rbf_solve_ex)       */
 };
 
 extern const gsl_sinterp_type *gsl_sinterp_rbf_gaussian;
@@ -234,6 +238,16 @@ int gsl_sinterp_set_devices(gsl_sinterp *interp, int n_devices);
 int gsl_sinterp_set_device_list(gsl_sinterp *interp, const int *devices, int n_devices);
 int gsl_sinterp_n_devices(const gsl_sinterp *interp);
 int gsl_sinterp_set_shape(gsl_sinterp *interp, double eps);
+/* Solver breadth (linalg/cholesky.c:392-537, linalg/pcholesky.c, linalg/lu.c:204): GSL_SINTERP_SOLVER_DEFAULT picks
+   by kernel class (Gaussian: Cholesky; thin-plate spline: shifted-SPD Cholesky, LU as fall-back); _CHOLESKY2 the
+   diagonally scaled Cholesky; _PCHOLESKY the pivoted LDL^T for semi-definite / nuggeted kernel matrices;
+   _LU_REFINE pivoted LU plus one refinement step.  gsl_sinterp_set_rcond(interp, 1) makes the next init estimate
+   the reciprocal condition number of the kernel matrix (Cholesky solvers; gsl_linalg_cholesky_rcond), read back
+   with gsl_sinterp_rcond (GSL_EINVAL when none is available). */
+int gsl_sinterp_set_solver(gsl_sinterp *interp, int solver);
+int gsl_sinterp_set_rcond(gsl_sinterp *interp, int want);
+int gsl_sinterp_rcond(const gsl_sinterp *interp, double *rcond);
+int gsl_sinterp_route(const gsl_sinterp *interp);
 int gsl_sinterp_set_tree_options(gsl_sinterp *interp, int init_flags, gsl_rng *rng);
 int gsl_sinterp_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *f);
 const char *gsl_sinterp_name(const gsl_sinterp *interp);

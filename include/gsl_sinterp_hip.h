@@ -135,6 +135,27 @@ int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, s
                               int *d_perm, int *h_signum);
 int gsl_sinterp_hip_lu_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_lu, size_t lda,
                            const int *d_perm, double *d_x);
+/* ---- solver breadth ---------------------------------- */
+/* gsl_linalg_cholesky_decomp2 (linalg/cholesky.c:392-429): S_i = 1/sqrt(A_ii) -> d_s, A <- diag(S) A diag(S),
+   then decomp1; svx2 (:431-462): x *= S, two sweeps, x *= S. */
+int gsl_sinterp_hip_cholesky_decomp2(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, double *d_s,
+                                     int *h_info);
+int gsl_sinterp_hip_cholesky_svx2(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda,
+                                  const double *d_s, double *d_x);
+/* gsl_linalg_cholesky_rcond (linalg/cholesky.c:499-537, linalg/condest.c:95-188): reciprocal 1-norm condition
+   number of the matrix whose factor (with the original kept in the strict upper triangle) is d_llt. */
+int gsl_sinterp_hip_cholesky_rcond(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda,
+                                   double *h_rcond);
+/* gsl_linalg_LU_refine (linalg/lu.c:204-252): one step of iterative refinement of d_x; d_work: n doubles. */
+int gsl_sinterp_hip_lu_refine(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_a, size_t lda, const double *d_lu,
+                              size_t ldlu, const int *d_perm, const double *d_b, double *d_x, double *d_work);
+/* gsl_linalg_pcholesky_decomp / _svx (linalg/pcholesky.c:71-229): P A P^T = L D L^T with diagonal pivoting, for
+   symmetric positive SEMI-definite matrices; L below the diagonal, D on it, the original in the strict upper
+   triangle; d_perm[n] (int32) as gsl_permutation content.  Bit-identical to the reference-order CPU algorithm. */
+int gsl_sinterp_hip_pcholesky_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *d_perm);
+int gsl_sinterp_hip_pcholesky_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_ldlt, size_t lda,
+                                  const int *d_perm, double *d_x);
+
 int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x,
                              size_t n, int dim, size_t xtda, const double *d_w,
                              const double *d_y, size_t m, size_t ytda, double *d_s);
@@ -146,6 +167,22 @@ int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, con
    reference's route, taken when the shifted matrix is not SPD or GSL_SINTERP_FORCE_LU=1). */
 int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
                               int dim, size_t xtda, double *d_phi, size_t lda, double *d_w, int *h_route);
+
+/* The same with an explicit solver (GSL_SINTERP_SOLVER_*) and an optional condition estimate:
+     DEFAULT    the routes above;
+     CHOLESKY2  scaled Cholesky, decomp2 + svx2 (route 4; SPD kernels);
+     PCHOLESKY  pivoted LDL^T (route 5; semi-definite / nuggeted kernel matrices);
+     LU_REFINE  pivoted LU + one gsl_linalg_LU_refine step (route 6; any kernel; needs a second n x n buffer,
+                allocated inside).
+   h_rcond (may be NULL): reciprocal condition number of the factored matrix for the Cholesky routes 1 and 4
+   (of the SCALED matrix for 4), NaN for the others. */
+#define GSL_SINTERP_SOLVER_DEFAULT 0
+#define GSL_SINTERP_SOLVER_CHOLESKY2 1
+#define GSL_SINTERP_SOLVER_PCHOLESKY 2
+#define GSL_SINTERP_SOLVER_LU_REFINE 3
+int gsl_sinterp_hip_rbf_solve_ex(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim,
+                                 size_t xtda, double *d_phi, size_t lda, double *d_w, int solver, double *h_rcond,
+                                 int *h_route);
 
 /* Level-3 building block of both factorisations, exposed for tests and roofline
    measurement (role of gsl_blas_dgemm / dsyrk, blas/blas.c:1334,1649):

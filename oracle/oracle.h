@@ -65,6 +65,15 @@ int oracle_lu_svx(size_t n, const double *lu, size_t lda, const size_t *perm, do
 int oracle_cholesky_decomp1(size_t n, double *a, size_t lda);                        /* linalg/cholesky.c:88 */
 int oracle_cholesky_svx(size_t n, const double *llt, size_t lda, double *x);         /* linalg/cholesky.c:163 */
 
+/* solver breadth */
+int oracle_cholesky_decomp2(size_t n, double *a, size_t lda, double *s);                        /* linalg/cholesky.c:392 */
+int oracle_cholesky_svx2(size_t n, const double *llt, size_t lda, const double *s, double *x); /* linalg/cholesky.c:431 */
+int oracle_cholesky_rcond(size_t n, const double *llt, size_t lda, double *rcond, double *work /* 3n */); /* :499, condest.c:95 */
+int oracle_lu_refine(size_t n, const double *a, size_t lda, const double *lu, size_t ldlu, const size_t *perm,
+                     const double *b, double *x, double *work);                                  /* linalg/lu.c:204 */
+int oracle_pcholesky_decomp(size_t n, double *a, size_t lda, size_t *perm);                     /* linalg/pcholesky.c:71 */
+int oracle_pcholesky_svx(size_t n, const double *ldlt, size_t lda, const size_t *perm, double *x); /* linalg/pcholesky.c:190 */
+
 /* ======================= simplex tree (oracle_simplex.c) ============= */
 #define ORACLE_TREE_DEFAULT 0
 #define ORACLE_TREE_NOSTANDARDIZE 1   /* linear_simplex.h:111 */

@@ -138,3 +138,152 @@ int oracle_cholesky_svx(size_t n, const double *llt, size_t lda, double *x)
   trsv_lower_trans(n, llt, lda, x, 1);             /* L^T x = c (cholesky.c:181) */
   return ORACLE_SUCCESS;
 }
+
+/* ---- solver breadth behind the same facade ---------------------------- */
+
+/* linalg/cholesky.c:312-338 (scale) + :355-388 (scale_apply) + :392-429 (decomp2) */
+int oracle_cholesky_decomp2(size_t n, double *a, size_t lda, double *s)
+{
+  for (size_t i = 0; i < n; i++) {
+    const double aii = a[i * lda + i];
+    s[i] = aii <= 0.0 ? 1.0 : 1.0 / sqrt(aii);
+  }
+  for (size_t j = 0; j < n; j++)
+    for (size_t i = j; i < n; i++) a[i * lda + j] *= s[i] * s[j];
+  return oracle_cholesky_decomp1(n, a, lda);
+}
+
+/* linalg/cholesky.c:431-462: x *= S; L c = x; L^T x = c; x *= S */
+int oracle_cholesky_svx2(size_t n, const double *llt, size_t lda, const double *s, double *x)
+{
+  for (size_t i = 0; i < n; i++) x[i] *= s[i];
+  oracle_cholesky_svx(n, llt, lda, x);
+  for (size_t i = 0; i < n; i++) x[i] *= s[i];
+  return ORACLE_SUCCESS;
+}
+
+/* linalg/cholesky.c:541-582: 1-norm of the ORIGINAL matrix kept in the strict upper triangle of LLT,
+   diagonal rebuilt from the rows of L (ddot, k ascending) */
+static double cholesky_norm1(size_t n, const double *llt, size_t lda, double *work)
+{
+  double max = 0.0;
+  for (size_t j = 0; j < n; j++) {
+    double sum = 0.0, ajj = 0.0;
+    for (size_t k = 0; k <= j; k++) ajj += llt[j * lda + k] * llt[j * lda + k];
+    for (size_t i = 0; i < j; i++) {
+      const double v = fabs(llt[i * lda + j]);
+      sum += v;
+      work[i] += v;
+    }
+    work[j] = sum + fabs(ajj);
+  }
+  for (size_t i = 0; i < n; i++) if (work[i] > max) max = work[i];
+  return max;
+}
+
+static double asum(size_t n, const double *x) { double r = 0.0; for (size_t i = 0; i < n; i++) r += fabs(x[i]); return r; }
+
+/* linalg/condest.c:95-188 (Hager / Higham estimator, at most 5 iterations), A^-1 = L^-T L^-1 (cholesky.c:584-604) */
+int oracle_cholesky_rcond(size_t n, const double *llt, size_t lda, double *rcond, double *work)
+{
+  *rcond = 0.0;
+  if (n == 0) return ORACLE_SUCCESS;
+  const double anorm = cholesky_norm1(n, llt, lda, work);
+  if (anorm == 0.0) return ORACLE_SUCCESS;
+  double *x = work, *v = work + n, *xi = work + 2 * n;
+  for (size_t i = 0; i < n; i++) x[i] = 1.0 / (double)n;
+  for (size_t i = 0; i < n; i++) v[i] = x[i];
+  oracle_cholesky_svx(n, llt, lda, v);
+  double gamma = asum(n, v), gamma_old;
+  for (size_t i = 0; i < n; i++) xi[i] = v[i] >= 0.0 ? 1 : -1;
+  for (size_t i = 0; i < n; i++) x[i] = xi[i];
+  oracle_cholesky_svx(n, llt, lda, x);
+  for (size_t k = 0; k < 5; k++) {
+    size_t j = 0;                                   /* idamax: first index of the largest |x| (source_iamax_r.h) */
+    double big = 0.0;
+    for (size_t i = 0; i < n; i++) if (fabs(x[i]) > big) { big = fabs(x[i]); j = i; }
+    for (size_t i = 0; i < n; i++) v[i] = 0.0;
+    v[j] = 1.0;
+    oracle_cholesky_svx(n, llt, lda, v);
+    gamma_old = gamma;
+    gamma = asum(n, v);
+    int same = 1;
+    for (size_t i = 0; i < n; i++) if ((v[i] >= 0.0) != (xi[i] >= 0.0)) { same = 0; break; }
+    if (same || gamma < gamma_old) break;
+    for (size_t i = 0; i < n; i++) xi[i] = v[i] >= 0.0 ? 1 : -1;
+    for (size_t i = 0; i < n; i++) x[i] = xi[i];
+    oracle_cholesky_svx(n, llt, lda, x);
+  }
+  double temp = 1.0;
+  for (size_t i = 0; i < n; i++) { x[i] = temp * (1.0 + (double)i / ((double)n - 1.0)); temp = -temp; }
+  oracle_cholesky_svx(n, llt, lda, x);
+  temp = 2.0 * asum(n, x) / (3.0 * (double)n);
+  if (temp > gamma) gamma = temp;
+  if (gamma != 0.0) *rcond = (1.0 / anorm) / gamma;
+  return ORACLE_SUCCESS;
+}
+
+/* linalg/lu.c:204-252: work = A x - b (dgemv, source_gemv_r.h:60-75: y = beta y, then += alpha * dot);
+   LU delta = work; x -= delta */
+int oracle_lu_refine(size_t n, const double *a, size_t lda, const double *lu, size_t ldlu, const size_t *perm,
+                     const double *b, double *x, double *work)
+{
+  if (oracle_lu_singular(n, lu, ldlu)) return ORACLE_EDOM;
+  for (size_t i = 0; i < n; i++) work[i] = b[i];
+  for (size_t i = 0; i < n; i++) work[i] *= -1.0;
+  for (size_t i = 0; i < n; i++) {
+    double temp = 0.0;
+    for (size_t j = 0; j < n; j++) temp += x[j] * a[lda * i + j];
+    work[i] += 1.0 * temp;
+  }
+  const int st = oracle_lu_svx(n, lu, ldlu, perm, work);
+  for (size_t i = 0; i < n; i++) x[i] += -1.0 * work[i];          /* daxpy(-1, work, x) */
+  return st;
+}
+
+/* linalg/pcholesky.c:71-130: outer-product LDL^T with diagonal pivoting (Golub & Van Loan alg. 4.2.2);
+   lower triangle holds L (unit diagonal implied) and D on the diagonal; original kept in the upper triangle */
+int oracle_pcholesky_decomp(size_t n, double *a, size_t lda, size_t *perm)
+{
+  for (size_t i = 0; i < n; i++)
+    for (size_t j = 0; j < i; j++) a[j * lda + i] = a[i * lda + j];          /* transpose_tricpy('L', 0) */
+  for (size_t i = 0; i < n; i++) perm[i] = i;
+  for (size_t k = 0; k < n; k++) {
+    size_t j = k;                                     /* gsl_vector_max_index over the diagonal k..n-1: first maximum */
+    double max = a[k * lda + k];
+    for (size_t i = k; i < n; i++) if (a[i * lda + i] > max) { max = a[i * lda + i]; j = i; }
+    { const size_t t = perm[k]; perm[k] = perm[j]; perm[j] = t; }
+    if (k != j) {                                     /* cholesky_common.c:34-86, lower triangle only */
+      const size_t ii = k, jj = j;
+      for (size_t c = 0; c < ii; c++) { double t = a[ii * lda + c]; a[ii * lda + c] = a[jj * lda + c]; a[jj * lda + c] = t; }
+      for (size_t c = ii + 1; c < jj; c++) { double t = a[jj * lda + c]; a[jj * lda + c] = a[c * lda + ii]; a[c * lda + ii] = t; }
+      for (size_t c = jj + 1; c < n; c++) { double t = a[c * lda + ii]; a[c * lda + ii] = a[c * lda + jj]; a[c * lda + jj] = t; }
+      { double t = a[ii * lda + ii]; a[ii * lda + ii] = a[jj * lda + jj]; a[jj * lda + jj] = t; }
+    }
+    if (k + 1 < n) {
+      const double alpha = a[k * lda + k], alphainv = 1.0 / alpha;
+      /* dsyr(Lower, -alphainv, v, m): m[i][j] += v[j] * (-alphainv * v[i]), j <= i  (source_syr.h:46-56) */
+      for (size_t i = k + 1; i < n; i++) {
+        const double tmp = -alphainv * a[i * lda + k];
+        for (size_t c = k + 1; c <= i; c++) a[i * lda + c] += a[c * lda + k] * tmp;
+      }
+      for (size_t i = k + 1; i < n; i++) a[i * lda + k] *= alphainv;
+    }
+  }
+  return ORACLE_SUCCESS;
+}
+
+/* linalg/pcholesky.c:190-229: x = P b; L w = x (unit); y = w / D; L^T z = y (unit); x = P^T z */
+int oracle_pcholesky_svx(size_t n, const double *ldlt, size_t lda, const size_t *perm, double *x)
+{
+  double *tmp = (double *)malloc((n ? n : 1) * sizeof(double));
+  for (size_t i = 0; i < n; i++) tmp[i] = x[perm[i]];
+  for (size_t i = 0; i < n; i++) x[i] = tmp[i];
+  trsv_lower_notrans(n, ldlt, lda, x, 0);
+  for (size_t i = 0; i < n; i++) x[i] /= ldlt[i * lda + i];
+  trsv_lower_trans(n, ldlt, lda, x, 0);
+  for (size_t i = 0; i < n; i++) tmp[perm[i]] = x[i];                           /* permute_vector_inverse */
+  for (size_t i = 0; i < n; i++) x[i] = tmp[i];
+  free(tmp);
+  return ORACLE_SUCCESS;
+}

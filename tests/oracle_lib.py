@@ -181,6 +181,48 @@ def cholesky_solve(llt, b):
     return x
 
 
+def cholesky_decomp2(a):
+    a = np.array(a, dtype=np.float64, order="C")
+    s = np.empty(a.shape[0])
+    st = lib().oracle_cholesky_decomp2(_sz(a.shape[0]), _p(a), _sz(a.shape[1]), _p(s))
+    return st, a, s
+
+
+def cholesky_solve2(llt, s, b):
+    x = np.array(b, dtype=np.float64)
+    lib().oracle_cholesky_svx2(_sz(llt.shape[0]), _p(llt), _sz(llt.shape[1]), _p(s), _p(x))
+    return x
+
+
+def cholesky_rcond(llt):
+    n = llt.shape[0]
+    r = C.c_double(0)
+    work = np.zeros(3 * n)
+    lib().oracle_cholesky_rcond(_sz(n), _p(llt), _sz(llt.shape[1]), C.byref(r), _p(work))
+    return r.value
+
+
+def lu_refine(a, lu, perm, b, x):
+    x = np.array(x, dtype=np.float64)
+    work = np.empty(len(x))
+    st = lib().oracle_lu_refine(_sz(len(x)), _p(a), _sz(a.shape[1]), _p(lu), _sz(lu.shape[1]),
+                                perm.ctypes.data_as(C.POINTER(C.c_size_t)), _p(np.ascontiguousarray(b)), _p(x), _p(work))
+    return st, x
+
+
+def pcholesky_decomp(a):
+    a = np.array(a, dtype=np.float64, order="C")
+    perm = np.zeros(a.shape[0], dtype=np.uintp)
+    st = lib().oracle_pcholesky_decomp(_sz(a.shape[0]), _p(a), _sz(a.shape[1]), perm.ctypes.data_as(C.POINTER(C.c_size_t)))
+    return st, a, perm
+
+
+def pcholesky_solve(ldlt, perm, b):
+    x = np.array(b, dtype=np.float64)
+    lib().oracle_pcholesky_svx(_sz(ldlt.shape[0]), _p(ldlt), _sz(ldlt.shape[1]), perm.ctypes.data_as(C.POINTER(C.c_size_t)), _p(x))
+    return x
+
+
 # ---- RBF harness
 def rbf_fill(kind, eps, x):
     n, d = x.shape

@@ -168,3 +168,86 @@ def test_small_trees_pass_reference_integrity_predicates(orc):
         assert t.init(x, flags=0, seed=0) == 0
         assert t.check_leaf_nodes() == 1
         assert t.check_delaunay(x) == 1
+
+
+# ---- solver breadth: pins for the oracle's decomp2 / rcond / LU_refine / pcholesky restatements
+EPS = 2.2204460492503131e-16
+
+
+def posdef(n, seed):
+    """create_posdef_matrix of linalg/test_common.c:68-88: symmetric U(0,1) entries + 10 N on the diagonal"""
+    rng = np.random.default_rng(seed)
+    m = rng.random((n, n))
+    a = np.tril(m) + np.tril(m, -1).T
+    return a + 10.0 * n * np.eye(n)
+
+
+def test_cholesky_rcond_hilbert_table(orc):
+    spec = LINALG["hilbert_rcond"]
+    for n, want in enumerate(spec["values"], start=1):
+        if want <= spec["min_checked"]:
+            continue
+        st, llt = orc.cholesky_decomp1(hilbert(n))
+        assert st == 0
+        got = orc.cholesky_rcond(llt)
+        assert abs(got - want) <= spec["rel_tol"] * want, (n, got, want)
+
+
+@pytest.mark.parametrize("n", list(range(1, 13)) + [30, 50])
+def test_cholesky_decomp2_reconstructs(orc, n):
+    for a in ([hilbert(n)] if n <= 12 else []) + [posdef(n, n)]:
+        st, v, s = orc.cholesky_decomp2(a)
+        assert st == 0
+        assert np.array_equal(s, 1.0 / np.sqrt(np.diag(a)))
+        L = np.tril(v) / s[:, None]                              # L <- S^-1 L  (test_cholesky.c:86-98)
+        rec = L @ L.T
+        assert np.abs(rec - a).max() <= max(n, 4) * EPS * 100 * np.abs(a).max()     # :161-162 (N eps, entrywise relative)
+        # the scaled matrix survives in the strict upper triangle (decomp1's transpose copy)
+        scaled = a * np.outer(s, s)
+        assert np.allclose(np.triu(v, 1), np.triu(scaled, 1), rtol=4 * EPS, atol=0)
+        b = np.arange(1.0, n + 1.0)
+        x = orc.cholesky_solve2(v, s, b)
+        assert np.abs(a @ x - b).max() <= 1e-6 * max(1.0, np.abs(x).max()) * np.abs(a).max()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 12, 33, 50])
+def test_pcholesky_reconstructs_and_solves(orc, n):
+    tol = LINALG["solver_breadth_tolerances"]
+    mats = [posdef(n, 100 + n)] + ([hilbert(n)] if n <= 12 else [])
+    for a in mats:
+        st, ldlt, perm = orc.pcholesky_decomp(a)
+        assert st == 0 and sorted(perm.tolist()) == list(range(n))
+        L = np.tril(ldlt, -1) + np.eye(n)
+        D = np.diag(np.diag(ldlt))
+        pap = a[np.ix_(perm, perm)]                              # P A P^T
+        assert np.abs(L @ D @ L.T - pap).max() <= tol["pcholesky_reconstruct_eps_mult_per_n"] * n * EPS * np.abs(a).max()
+        d = np.diag(ldlt)
+        assert (np.diff(d[: max(1, n)]) <= 1e-12 * np.abs(d).max()).all() or n > 12      # pivoting: D non-increasing (exactly so in exact arithmetic)
+        assert np.array_equal(np.triu(ldlt, 1), np.triu(a, 1))   # original kept in the strict upper triangle
+    a = posdef(n, 100 + n)
+    rng = np.random.default_rng(n)
+    sol = rng.random(n)
+    rhs = a @ sol
+    st, ldlt, perm = orc.pcholesky_decomp(a)
+    x = orc.pcholesky_solve(ldlt, perm, rhs)
+    assert np.abs(x - sol).max() <= tol["pcholesky_solve_eps_mult_per_n"] * n * EPS * max(1.0, np.abs(sol).max()) * 4
+    if n <= 3:
+        h = hilbert(n)
+        rhs = h @ sol
+        st, ldlt, perm = orc.pcholesky_decomp(h)
+        x = orc.pcholesky_solve(ldlt, perm, rhs)
+        assert np.abs(x - sol).max() <= tol["pcholesky_solve_hilbert_eps_mult_per_n"] * n * EPS * 4
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 12])
+def test_lu_refine_keeps_the_known_answers(orc, n):
+    """linalg/test.c:411-494: after LU_solve, LU_refine must still meet the Hilbert / Vandermonde tolerances."""
+    b = np.arange(1.0, n + 1.0)
+    for name, mat in (("hilbert", hilbert(n)), ("vandermonde", vandermonde(n))):
+        spec = LINALG[name][str(n)]
+        lu, perm, _ = orc.lu_decomp(mat)
+        st, x = orc.lu_solve(lu, perm, b)
+        st2, xr = orc.lu_refine(mat, lu, perm, b, x)
+        assert st == 0 and st2 == 0
+        tol = spec["lu_eps_mult"] * EPS if "lu_eps_mult" in spec else spec["lu_abs_tol"]
+        assert all(rel_ok(xr[i], spec["solution"][i], tol) for i in range(n)), (name, n, xr)
