@@ -161,3 +161,18 @@ def test_facade_argument_errors_without_gpu(pkg):
     assert s.init(np.zeros((8, 3)), np.zeros(8)) == pkg.capi.GSL_EINVAL
     st, val = s.eval_e([0.0, 0.0])
     assert st != 0 and np.isnan(val)               # not initialised -> status + NaN, never a CPU answer
+
+
+def test_docs_are_sane_text_files():
+    """DESIGN.md was once corrupted into a 13 MB file by a doc-update slip: keep the docs small, line-structured text."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("DESIGN.md", "INTEGRATION.md", "README.md"):
+        path = os.path.join(root, name)
+        size = os.path.getsize(path)
+        text = open(path, encoding="utf-8").read()
+        assert 1000 < size < 200_000, (name, size)
+        assert text.count("\n") < 2000 and text.startswith("#"), name
+    design = open(os.path.join(root, "DESIGN.md"), encoding="utf-8").read()
+    for sec in ("## 1.", "## 2.", "## 3.", "## 4.", "## 5.", "## 6.", "## 7."):
+        assert design.count("\n" + sec) == 1, sec

@@ -28,6 +28,7 @@ def test_host_c_and_oracle_under_asan_ubsan():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_host_tree.py"),
                         os.path.join(ROOT, "tests", "test_oracle_golden.py"),
+                        os.path.join(ROOT, "tests", "test_io_formats.py"),
                         os.path.join(ROOT, "tests", "test_c_dropin.py")],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
