@@ -384,11 +384,18 @@ __device__ __forceinline__ void decode_tile(const GemmArgs &g, unsigned tile, in
    The small 64x64 tile spends only 0.43 us of MFMA work per 16-wide step -- less than a DMA round trip and
    comparable to a barrier -- so it runs SS = 4, ST = 2 (128 KiB): a K = 128 update has its WHOLE operand
    panel in flight from the first instruction and crosses two barriers instead of eight. */
-template <int BM, int BN, int WM, int WN, int SS = 1, int ST = DM_STAGES>
+/* PIPE (ST = 3, SS = 1 only): the K loop is software-pipelined ACROSS its barrier.  In the plain loop every wave
+   meets at the barrier with an empty MFMA queue and must then wait out an LDS round trip before its first
+   MFMA of the new step: a bubble of a few hundred cycles per 8192-cycle step on every SIMD.  Here the last
+   quarter of a step's MFMAs (its fragments are already in registers) is issued AFTER the barrier and after the
+   first fragment loads of the next step, so the matrix pipe stays fed through the rendezvous; the barrier also
+   moves one quarter-step earlier relative to the DMA ring, which now runs three steps ahead instead of two. */
+template <int BM, int BN, int WM, int WN, int SS = 1, int ST = DM_STAGES, bool PIPE = false>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 1)
 gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 {
   static_assert(ST == 3 || ST == 2, "ring depth");
+  static_assert(!PIPE || (ST == 3 && SS == 1), "pipelined loop: three-deep ring of single steps");
   constexpr int WCOLS = BN / WN;                        /* waves along n */
   constexpr int NW = (BM / WM) * WCOLS;
   constexpr int NT = NW * 64;                           /* threads */
@@ -470,6 +477,80 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
         for (int j = 0; j < FN; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
       __syncthreads();                                   /* the ring is free: previous segment fully read */
+      if constexpr (PIPE) {
+        auto wait_keep = [&](int groups) {               /* all but the last `groups` issued groups have landed */
+          if (groups >= 2) {
+            if constexpr (PER_GROUP == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (PER_GROUP == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          } else if (groups == 1) {
+            if constexpr (PER_GROUP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (PER_GROUP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto load_frag = [&](int stage, int kk, double (&af)[FM], double (&bf)[FN]) {
+          const double *a_base = sA + stage * A_TILE + arow;
+          const double *b_base = sB + stage * B_TILE + brow;
+#pragma unroll
+          for (int i = 0; i < FM; i++) af[i] = a_base[i * 16 * GT_BK + koff[kk]];
+#pragma unroll
+          for (int j = 0; j < FN; j++) bf[j] = b_base[j * 16 * GT_BK + koff[kk]];
+        };
+        auto mma = [&](const double (&af)[FM], const double (&bf)[FN]) {
+#pragma unroll
+          for (int i = 0; i < FM; i++)
+#pragma unroll
+            for (int j = 0; j < FN; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        };
+        const unsigned nst = s1 - s0;
+        issue(0, (size_t)s0 * GK);
+        if (nst > 1) issue(1, (size_t)(s0 + 1) * GK);
+        if (nst > 2) issue(2, (size_t)(s0 + 2) * GK);
+        wait_keep(nst > 2 ? 2 : (int)nst - 1);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        double af0[FM], bf0[FN], af1[FM], bf1[FN];
+        load_frag(0, 0, af0, bf0);
+        /* all steps but the last: the rendezvous sits between the third and the fourth quarter of the step */
+        for (unsigned rel = 0; rel + 1 < nst; rel++) {
+          const int stage = (int)(rel % 3);
+          load_frag(stage, 1, af1, bf1);
+          mma(af0, bf0);
+          load_frag(stage, 2, af0, bf0);
+          mma(af1, bf1);
+          load_frag(stage, 3, af1, bf1);
+          mma(af0, bf0);
+          /* (stage, 3) is in af1/bf1; every LDS read of `stage` has returned; stage+1 has landed for this wave once
+             only the group issued after it (rel+2, if it exists) is outstanding; after the barrier that holds for
+             every wave, and `stage` may be refilled */
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          /* tell the compiler's s_waitcnt pass that af1 / bf1 are settled HERE (it cannot see through the asm wait
+             above and would otherwise put a full lgkmcnt(0) between the next step's loads and the deferred MFMAs) */
+#pragma unroll
+          for (int i = 0; i < FM; i++) asm volatile("" : "+v"(af1[i]));
+#pragma unroll
+          for (int j = 0; j < FN; j++) asm volatile("" : "+v"(bf1[j]));
+          wait_keep(rel + 2 < nst ? 1 : 0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          if (rel + 3 < nst) issue(stage, (size_t)(s0 + rel + 3) * GK);
+          load_frag((int)((rel + 1) % 3), 0, af0, bf0);
+          __builtin_amdgcn_sched_barrier(0);             /* keep the loads in front of the deferred MFMAs */
+          mma(af1, bf1);                                 /* runs while the new fragments fly (counted lgkmcnt: no merge of paths here) */
+        }
+        {
+          const int stage = (int)((nst - 1) % 3);
+          load_frag(stage, 1, af1, bf1);
+          mma(af0, bf0);
+          load_frag(stage, 2, af0, bf0);
+          mma(af1, bf1);
+          load_frag(stage, 3, af1, bf1);
+          mma(af0, bf0);
+          mma(af1, bf1);
+        }
+      } else {
       issue(0, (size_t)s0 * GK);
       if (s0 + 1 < s1) issue(1, (size_t)(s0 + 1) * GK);
       for (unsigned s = s0; s < s1; s++) {
@@ -513,6 +594,7 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
             issue(stage, (size_t)(s + 2) * GK);
           }
         }
+      }
       }
     }
 
@@ -745,10 +827,19 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       total64 = (unsigned long long)(tiles - x.dp_rounds * G) * x.steps;
       if (total64 < 0x7fffffffull) {
       x.total = (unsigned)total64; x.base = x.total / G; x.rem = x.total % G;
-      if (cfg == 0) {
+      static const bool no_pipe = getenv("GSL_SINTERP_NO_GEMM_PIPE") && getenv("GSL_SINTERP_NO_GEMM_PIPE")[0] == '1';
+      if (cfg == 0 && !no_pipe) {
+        const size_t lds = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<256, 128, 64, 64, 1, 3, true>, (int)lds); if (ast) return ast; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<256, 128, 64, 64, 1, 3, true>), dim3(G), dim3(512), lds, ctx->stream, h, x);
+      } else if (cfg == 0) {
         const size_t lds = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);
         { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<256, 128, 64, 64>, (int)lds); if (ast) return ast; }
         hipLaunchKernelGGL((gemm_minus_streamk_kernel<256, 128, 64, 64>), dim3(G), dim3(512), lds, ctx->stream, h, x);
+      } else if (cfg == 1 && !no_pipe) {
+        const size_t lds = (size_t)DM_STAGES * (128 + 128) * GT_BK * sizeof(double);
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<128, 128, 64, 64, 1, 3, true>, (int)lds); if (ast) return ast; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<128, 128, 64, 64, 1, 3, true>), dim3(G), dim3(256), lds, ctx->stream, h, x);
       } else if (cfg == 1) {
         const size_t lds = (size_t)DM_STAGES * (128 + 128) * GT_BK * sizeof(double);
         { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<128, 128, 64, 64>, (int)lds); if (ast) return ast; }
