@@ -44,6 +44,7 @@ struct gsl_sinterp_hip_ctx {
   /* stream-K GEMM (gemm.hip): one partial-tile slot + one flag per persistent workgroup */
   double *d_sk_partial;
   unsigned *d_sk_flags;
+  unsigned *d_sk_tiles;     /* XCD super-tile order of the current large update (tile id -> tm, tn) */
   int sk_wgs;               /* persistent workgroups = CUs of the device; 0 = not prepared */
   /* dataflow sweeps (chol.hip): [0] = epoch of the last completed sweep, [1 + J] = epoch in which
      block J was last published.  Never reset (no memset node in the captured graphs): a sweep
@@ -115,6 +116,10 @@ struct SinterpExclusive {      /* RAII form: every return path of an entry point
   SinterpExclusive &operator=(const SinterpExclusive &) = delete;
 };
 #define EXCLUSIVE_SECTION(ctx) SinterpExclusive _excl(ctx); if (_excl.st) return _excl.st
+
+/* rbf.hip: the fill with the option of writing the tiles on / below the diagonal only */
+int sinterp_rbf_fill_ex(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim, size_t xtda,
+                        double *d_phi, size_t lda, int lower_only);
 
 /* grow-only workspace owned by the context */
 int sinterp_workspace(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);

@@ -40,6 +40,7 @@ struct GemmArgs {
   int lower_only;
   int tiles_m, tiles_n;
   unsigned n_active;   /* tiles that are launched: all, or the lower trapezoid when lower_only */
+  const unsigned *tile_table;   /* stream-K: tile id -> (tm << 16 | tn) in XCD super-tile order, NULL = formula order */
 };
 
 __device__ __forceinline__ double2 ld2(const double *p, bool ok0, bool ok1, bool vec)
@@ -197,6 +198,7 @@ gemm_minus_kernel(GemmArgs g)
    per-lane SOURCE address of the DMA and to the fragment read, so the (row = lane&15,
    k = lane>>4) ds_read_b64 stays bank-conflict free. */
 #define DM_STAGES 3
+#define SK_TILE_TABLE_ENTRIES 262144u   /* tile-order table of the stream-K kernel (1 MiB) */
 
 __device__ __forceinline__ void dma16(const double *gsrc, double *ldst)
 {
@@ -429,7 +431,11 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
     const unsigned s0 = dp ? 0u : it - tile_first;
     const unsigned s1 = dp ? x.steps : (it_end < tile_end ? it_end - tile_first : x.steps);
     int tm, tn;
-    decode_tile<BM, BN>(g, dp ? round * G + gl : dp_tiles + tile, tm, tn);
+    {
+      const unsigned tid_ = dp ? round * G + gl : dp_tiles + tile;
+      if (g.tile_table) { const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)g.tile_table[tid_]); tm = (int)(e >> 16); tn = (int)(e & 0xffffu); }
+      else decode_tile<BM, BN>(g, tid_, tm, tn);
+    }
     const size_t row0 = (size_t)tm * BM, col0 = (size_t)tn * BN;
 
     double4_t acc[FM][FN];
@@ -662,6 +668,53 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
   }
 }
 
+/* NEGATIVE RESULT, kept as an opt-in knob (GSL_SINTERP_SUPERTILE=1).  Tile order for the whole-tile rounds of a
+   large update.  In round r the 32 workgroups of an XCD (which share its 4 MiB L2) hold 32 CONSECUTIVE tile ids.
+   With ids running along a tile row those 32 tiles share one A panel but need 32 different B panels: per K-step
+   the XCD pulls (1 x BM + 32 x BN) x 16 doubles through the fabric = 9.7 GB for the 8192^3 launch, which is what
+   the counters show (10.8 GB; algorithmic bytes 1.07 GB).  The idea: let consecutive ids walk SR x SC = 4 x 8
+   SUPER-TILES (row-major inside, super-tiles row by row), so an XCD's 32 tiles need 4 A panels + 8 B panels,
+   (4 BM + 8 BN) x 16 doubles per K-step, 2.1x fewer on paper.  Measured: 12.0 GB and 1 % slower -- the 32-way
+   simultaneous reuse of ONE panel is what the L2 delivers; 4- and 8-way reuse spread over 12 panels is not.  Any shape:
+   tiles outside the (lower-trapezoid) domain are skipped, a prefix sum over the super-tiles gives each its first id.
+   One workgroup; rr = BM / BN. */
+#define ST_SR 4
+#define ST_SC 8
+__global__ void __launch_bounds__(1024)
+gemm_tile_order_kernel(int tiles_m, int tiles_n, int lower_only, unsigned rr, unsigned *__restrict__ table)
+{
+  __shared__ unsigned s_cnt[1024];
+  const int sup_m = (tiles_m + ST_SR - 1) / ST_SR, sup_n = (tiles_n + ST_SC - 1) / ST_SC;
+  const int nsup = sup_m * sup_n, t = threadIdx.x;
+  auto valid = [&](int tm, int tn) -> bool {
+    if (tm >= tiles_m || tn >= tiles_n) return false;
+    if (!lower_only) return true;
+    const unsigned lim = rr * (unsigned)(tm + 1);                     /* row tm of tiles holds min(rr (tm+1), tiles_n) tiles */
+    return (unsigned)tn < (lim < (unsigned)tiles_n ? lim : (unsigned)tiles_n);
+  };
+  unsigned cnt = 0;
+  const int sm = t / sup_n, sn = t % sup_n;
+  if (t < nsup)
+    for (int a = 0; a < ST_SR; a++)
+      for (int b = 0; b < ST_SC; b++) cnt += valid(sm * ST_SR + a, sn * ST_SC + b);
+  s_cnt[t] = cnt;
+  __syncthreads();
+  /* exclusive scan over <= 1024 entries (Hillis-Steele; one launch per large update, off the critical path) */
+  for (int off = 1; off < 1024; off <<= 1) {
+    const unsigned v = t >= off ? s_cnt[t - off] : 0u;
+    __syncthreads();
+    s_cnt[t] += v;
+    __syncthreads();
+  }
+  unsigned pos = s_cnt[t] - cnt;
+  if (t < nsup)
+    for (int a = 0; a < ST_SR; a++)
+      for (int b = 0; b < ST_SC; b++) {
+        const int tm = sm * ST_SR + a, tn = sn * ST_SC + b;
+        if (valid(tm, tn)) table[pos++] = ((unsigned)tm << 16) | (unsigned)tn;
+      }
+}
+
 int sinterp_streamk_prepare(gsl_sinterp_hip_ctx *ctx)
 {
   if (ctx->sk_wgs) return ST_SUCCESS;
@@ -672,6 +725,7 @@ int sinterp_streamk_prepare(gsl_sinterp_hip_ctx *ctx)
   if (cus <= 0) return ST_SUCCESS;
   HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_partial, (size_t)cus * 256 * GT_BN * sizeof(double)));
   HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_flags, (size_t)cus * sizeof(unsigned)));
+  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_tiles, SK_TILE_TABLE_ENTRIES * sizeof(unsigned)));
   HIP_OK(ctx, hipMemset(ctx->d_sk_flags, 0, (size_t)cus * sizeof(unsigned)));
   HIP_OK(ctx, hipDeviceSynchronize());
   ctx->sk_wgs = cus;
@@ -756,6 +810,7 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   GemmArgs g;
   g.m = m; g.n = n; g.k = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.lower_only = lower_only;
+  g.tile_table = NULL;
   g.tiles_m = (int)((m + GT_BM - 1) / GT_BM);
   g.tiles_n = (int)((n + GT_BN - 1) / GT_BN);
   if (lower_only && g.tiles_m < g.tiles_n) g.tiles_n = g.tiles_m;   /* columns right of the square part are all above the diagonal */
@@ -825,6 +880,16 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       static const bool no_hybrid = getenv("GSL_SINTERP_NO_HYBRID_SK") && getenv("GSL_SINTERP_NO_HYBRID_SK")[0] == '1';
       x.dp_rounds = (!no_hybrid && tiles / G >= 2) ? tiles / G - 1 : 0;
       total64 = (unsigned long long)(tiles - x.dp_rounds * G) * x.steps;
+      h.tile_table = NULL;
+      /* opt-in: measured on MI355X (rocprofv3 FETCH_SIZE, 8192^3 lower): 12.0 GB through the fabric with the super-tile
+         order against 10.8 GB with ids running along tile rows, and 1 % slower -- the model below does not hold */
+      static const bool use_super = getenv("GSL_SINTERP_SUPERTILE") && getenv("GSL_SINTERP_SUPERTILE")[0] == '1';
+      if (use_super && x.dp_rounds >= 1 && cfg != 2 && ctx->d_sk_tiles && tiles <= SK_TILE_TABLE_ENTRIES && h.tiles_m < 65536 &&
+          h.tiles_n < 65536 && ((h.tiles_m + ST_SR - 1) / ST_SR) * ((h.tiles_n + ST_SC - 1) / ST_SC) <= 1024) {
+        hipLaunchKernelGGL(gemm_tile_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, h.tiles_m, h.tiles_n, lower_only,
+                           cfg == 0 ? 2u : 1u, ctx->d_sk_tiles);
+        h.tile_table = ctx->d_sk_tiles;
+      }
       if (total64 < 0x7fffffffull) {
       x.total = (unsigned)total64; x.base = x.total / G; x.rem = x.total % G;
       static const bool no_pipe = getenv("GSL_SINTERP_NO_GEMM_PIPE") && getenv("GSL_SINTERP_NO_GEMM_PIPE")[0] == '1';

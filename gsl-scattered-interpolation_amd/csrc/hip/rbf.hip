@@ -118,8 +118,11 @@ __device__ __forceinline__ void load_tables(double *s_t0, double *s_lt, int kind
 /* fill: block = 256 threads -> 16 rows x 128 cols, 2 columns (16 B) per lane */
 template <int KIND, int DIM>
 __global__ void __launch_bounds__(256)
-rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, double *__restrict__ phi, size_t lda)
+rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, double *__restrict__ phi, size_t lda, int lower_only)
 {
+  /* lower_only: tiles that lie entirely above the diagonal are not written (the Cholesky route reads the lower
+     triangle only; half of the HBM writes of the fill) */
+  if (lower_only && (size_t)blockIdx.x * 128 > (size_t)blockIdx.y * 16 + 15) return;
   __shared__ double s_t0[KIND == GSL_SINTERP_RBF_GAUSSIAN ? TBL_N : 1];
   __shared__ __attribute__((aligned(16))) double s_lt[KIND == GSL_SINTERP_RBF_TPS ? LOG_N * 2 : 2];   /* one copy: the fill is HBM-write bound */
   load_tables<1>(s_t0, s_lt, KIND);
@@ -426,13 +429,13 @@ static double kernel_coef(int kind, double eps)
 
 template <int KIND>
 static int launch_fill(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x, size_t n, int dim, size_t xtda,
-                       double *d_phi, size_t lda)
+                       double *d_phi, size_t lda, int lower_only)
 {
   dim3 grid((unsigned)((n + 127) / 128), (unsigned)((n + 15) / 16));
   switch (dim) {
-    case 1: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 1>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda); break;
-    case 2: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 2>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda); break;
-    default: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 3>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda); break;
+    case 1: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 1>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda, lower_only); break;
+    case 2: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 2>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda, lower_only); break;
+    default: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 3>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda, lower_only); break;
   }
   LAUNCH_CHECK(ctx);
   return ST_SUCCESS;
@@ -440,6 +443,12 @@ static int launch_fill(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x,
 
 extern "C" int gsl_sinterp_hip_rbf_fill(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
                                         int dim, size_t xtda, double *d_phi, size_t lda)
+{
+  return sinterp_rbf_fill_ex(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, 0);
+}
+
+int sinterp_rbf_fill_ex(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim, size_t xtda,
+                        double *d_phi, size_t lda, int lower_only)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
@@ -451,8 +460,8 @@ extern "C" int gsl_sinterp_hip_rbf_fill(gsl_sinterp_hip_ctx *ctx, int kind, doub
   int st = ensure_tables(ctx);
   if (st) return st;
   const double coef = kernel_coef(kind, eps);
-  return kind == GSL_SINTERP_RBF_GAUSSIAN ? launch_fill<GSL_SINTERP_RBF_GAUSSIAN>(ctx, coef, d_x, n, dim, xtda, d_phi, lda)
-                                          : launch_fill<GSL_SINTERP_RBF_TPS>(ctx, coef, d_x, n, dim, xtda, d_phi, lda);
+  return kind == GSL_SINTERP_RBF_GAUSSIAN ? launch_fill<GSL_SINTERP_RBF_GAUSSIAN>(ctx, coef, d_x, n, dim, xtda, d_phi, lda, lower_only)
+                                          : launch_fill<GSL_SINTERP_RBF_TPS>(ctx, coef, d_x, n, dim, xtda, d_phi, lda, lower_only);
 }
 
 template <int KIND, int TPT>

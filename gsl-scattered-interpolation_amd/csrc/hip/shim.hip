@@ -81,6 +81,7 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_cent) (void)hipFree(ctx->d_cent);
   if (ctx->d_sk_partial) (void)hipFree(ctx->d_sk_partial);
   if (ctx->d_sk_flags) (void)hipFree(ctx->d_sk_flags);
+  if (ctx->d_sk_tiles) (void)hipFree(ctx->d_sk_tiles);
   if (ctx->d_tf) (void)hipFree(ctx->d_tf);
   if (ctx->d_xq) (void)hipFree(ctx->d_xq);
   if (ctx->d_jumpt) (void)hipFree(ctx->d_jumpt);

@@ -139,8 +139,18 @@ static int host_solve(int k, double *S, double *g)
   return 0;
 }
 
+static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim, size_t xtda,
+                          double *d_phi, size_t lda, double *d_w, int *h_route, bool keep_upper);
+
 extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
                                          int dim, size_t xtda, double *d_phi, size_t lda, double *d_w, int *h_route)
+{
+  /* d_phi is scratch here: the Gaussian route fills and factors the lower triangle only */
+  return rbf_solve_impl(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, h_route, false);
+}
+
+static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim, size_t xtda,
+                          double *d_phi, size_t lda, double *d_w, int *h_route, bool keep_upper)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
@@ -149,7 +159,9 @@ extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, dou
   REQUIRE(ctx, n == 0 || (d_x && d_phi && d_w), ST_EFAULT);
   if (h_route) *h_route = 0;
   if (n == 0) return ST_SUCCESS;
-  int st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);
+  /* thin-plate spline: the shift and the row norms need the full matrix; Gaussian: the Cholesky reads the lower
+     triangle only, the upper one (the "original kept above the diagonal" of cholesky.c:103) only when asked for */
+  int st = sinterp_rbf_fill_ex(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, kind == GSL_SINTERP_RBF_GAUSSIAN && !keep_upper);
   if (st) return st;
   int info = 0;
 
@@ -244,7 +256,7 @@ extern "C" int gsl_sinterp_hip_rbf_solve_ex(gsl_sinterp_hip_ctx *ctx, int kind, 
     if (!h_rcond || kind != GSL_SINTERP_RBF_GAUSSIAN)
       return gsl_sinterp_hip_rbf_solve(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, h_route);
     int route = 0;
-    int st = gsl_sinterp_hip_rbf_solve(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, &route);
+    int st = rbf_solve_impl(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, &route, true);
     if (h_route) *h_route = route;
     if (st || route != 1) return st;
     return gsl_sinterp_hip_cholesky_rcond(ctx, n, d_phi, lda, h_rcond);     /* d_phi holds L + the original above the diagonal */
