@@ -75,10 +75,22 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # Rehearsal aids for a ONE-GPU box (never set by the driver): BENCH_FORCE_DEVICE puts every rank on that
+        # ordinal and BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU), so the whole
+        # multi-rank control flow -- shards, rank-0-only init, broadcasts, barriers, max-reduction, rank-0 JSON --
+        # runs with N processes sharing one card; the numbers of such a run mean nothing.
+        forced = os.environ.get("BENCH_FORCE_DEVICE")
+        if forced is not None:
+            self.local_rank = int(forced)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        self.rehearsal = forced is not None or backend != "nccl"
         if self.world > 1:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(self.local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))   # nccl == RCCL on ROCm
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))   # nccl == RCCL on ROCm
+            else:
+                dist.init_process_group(backend=backend)
         assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
         assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
         torch.cuda.set_device(self.local_rank)
@@ -265,6 +277,8 @@ def main():
             if k in head:
                 out[k] = head[k]
         out["extra"] = dict(head["extra"], other_configs=others)
+        if env.rehearsal:
+            out["extra"]["REHEARSAL"] = "ranks share one GPU / non-RCCL backend: control-flow check only, the numbers are meaningless"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(CONFIGS[args.config], head["n_centres"], head["dim"], head["targets_total"])
         print(json.dumps(out))

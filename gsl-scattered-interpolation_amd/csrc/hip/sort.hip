@@ -14,6 +14,7 @@
  */
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 __device__ __forceinline__ unsigned long long dkey(double v)   /* monotone double -> uint64 */
 {
@@ -223,7 +224,28 @@ int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   return ST_SUCCESS;
 }
 
-/* cell c occupies perm[offset[c] .. offset[c+1]): order every cell's run by original index */
+/* cell c occupies perm_in[offset[c] .. offset[c+1]) in the (run-to-run varying) order of the atomic scatter; the
+   sweep must see each cell's centres in ORIGINAL index order (fixed summation order).  One thread per centre k:
+   its place inside the run is the number of run members with a smaller index -- a rank sort, no serial pass
+   (the round-1 kernel sorted every run with one thread by insertion in global memory: 196 us at N = 16384 for a
+   few KB of data, 9 % of C3's sweep).  A degenerate cell (thousands of centres) keeps the scatter order. */
+__global__ void __launch_bounds__(256)
+cell_rank_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ slot, const unsigned *__restrict__ offset,
+                 const int *__restrict__ perm_in, int *__restrict__ perm_out, size_t n)
+{
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const unsigned c = cellid[k], b = offset[c], e = offset[c + 1];
+  unsigned rank = slot[k];
+  if (e - b <= 2048u) {
+    rank = 0;
+    for (unsigned j = b; j < e; j++) rank += (unsigned)(perm_in[j] < (int)k);
+  }
+  perm_out[b + rank] = (int)k;
+}
+
+/* cell c occupies perm[offset[c] .. offset[c+1]): order every cell's run by original index (superseded by
+   cell_rank_kernel; kept for GSL_SINTERP_SERIAL_CELL_ORDER=1) */
 __global__ void __launch_bounds__(256)
 cell_order_kernel(const unsigned *__restrict__ offset, unsigned ncell, int *__restrict__ perm)
 {
@@ -255,11 +277,12 @@ int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, 
   size_t ncell = 1;
   for (int c = 0; c < dim; c++) ncell *= (size_t)g;
   void *buf = NULL;
-  const size_t bytes = 64 + n * 4 + n * 4 + n * 4 + (ncell + 1) * 4 + (ncell / 1024 + 8) * 4;
+  const size_t bytes = 64 + n * 4 + n * 4 + n * 4 + n * 4 + (ncell + 1) * 4 + (ncell / 1024 + 8) * 4;
   int st = sinterp_sortbuf2(ctx, bytes, &buf);
   if (st) return st;
   unsigned long long *box = (unsigned long long *)buf;
-  int *perm = (int *)((char *)buf + 64);
+  int *perm_sorted = (int *)((char *)buf + 64);
+  int *perm = perm_sorted + n;
   unsigned *cellid = (unsigned *)(perm + n);
   unsigned *slot = cellid + n;
   unsigned *count = slot + n;
@@ -273,10 +296,18 @@ int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, 
   launch_cell_scan(ctx, count, ncell, count + ncell + 1);
   hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)cellid,
                      (const unsigned *)slot, n, (const unsigned *)count, perm);
-  hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned *)count,
-                     (unsigned)ncell, perm);
+  static const bool serial_order = getenv("GSL_SINTERP_SERIAL_CELL_ORDER") && getenv("GSL_SINTERP_SERIAL_CELL_ORDER")[0] == '1';
+  if (serial_order) {
+    hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned *)count,
+                       (unsigned)ncell, perm);
+    LAUNCH_CHECK(ctx);
+    *d_perm_out = perm;
+    return ST_SUCCESS;
+  }
+  hipLaunchKernelGGL(cell_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned *)cellid,
+                     (const unsigned *)slot, (const unsigned *)count, (const int *)perm, perm_sorted, n);
   LAUNCH_CHECK(ctx);
-  *d_perm_out = perm;
+  *d_perm_out = perm_sorted;
   return ST_SUCCESS;
 }
 
