@@ -1098,6 +1098,208 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
   }
 }
 
+/* ---- two consecutive blocks of the sweep per workgroup -----------------------------------------
+   NEGATIVE RESULT, opt-in (GSL_SINTERP_TRSV_PAIRS=1): halving the grid-wide hand-offs does not shorten the sweep --
+   the second block's solve inside the workgroup (reduce, barrier, 64 x 64 matvec, barrier: ~1 us) plus the second
+   poll per unit cost what the hand-off cost (C3 init 33.1 -> 33.6 ms).  The chain is bound by the per-block
+   reduce + matvec + two barriers as much as by the hop.
+   The dependent chain of the kernel above is one grid-wide hand-off (sc1 store -> sc1 poll, ~2.3 us) per
+   64-row block: 256 steps per sweep at N = 16384, 0.6 ms for 1.07 GB of matrix.  Here a workgroup owns the
+   blocks 2u and 2u+1 of the sweep order: both block rows stream the tiles of the earlier blocks together (two
+   tiles per received x_J), block 2u is solved, its x goes to block 2u+1 through LDS (no hand-off: the tile
+   T(2u+1, 2u) and W_{2u+1} were fetched at the start), block 2u+1 is solved, both are published.  Half the
+   grid-wide steps; a workgroup still only waits on blocks of workgroups dispatched before it. */
+__global__ void __launch_bounds__(256)
+trsv_dataflow_pair_kernel(const double *__restrict__ T, size_t ldt, size_t n, const double *__restrict__ b, double *xout, size_t ldb,
+                          int nrhs, int mode, const double *__restrict__ Dinv, unsigned *tf, unsigned long long *xq, unsigned nblk)
+{
+  constexpr int NQ = (TRSV_MAXR * TS + 255) / 256;
+  const unsigned want = __hip_atomic_load(tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const size_t npad = (size_t)nblk * TS;
+  __shared__ double sx[2][TRSV_MAXR][TS];
+  __shared__ double sxl[TRSV_MAXR][TS];                  /* x of this workgroup's first block, for its second */
+  __shared__ double sW[TS][TS + 1];
+  __shared__ double srhs[TRSV_MAXR][TS];
+  __shared__ double s_part[TRSV_MAXR][4][TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rsub = lane >> 3, c8 = (lane & 7) * 8;
+  const unsigned nunits = (nblk + 1) / 2;
+
+  /* this thread's slice of tile T(I, J) (the layouts of trsv_dataflow_kernel) */
+  auto load_tile = [&](double (&tt)[16], unsigned I, unsigned J) {
+    const size_t i0 = (size_t)I * TS, j0 = (size_t)J * TS;
+    const int nbI = (int)((n - i0) < TS ? (n - i0) : TS);
+    if (mode == 1) {
+#pragma unroll
+      for (int jj = 0; jj < 16; jj++) {
+        const size_t jr = j0 + wave * 16 + jj;
+        tt[jj] = (jr < n && lane < nbI) ? T[jr * ldt + i0 + lane] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {
+        const size_t i = i0 + pass * 32 + wave * 8 + rsub;
+        const double *row = T + i * ldt + j0 + c8;
+        if (i < n && j0 + TS <= n && ((((uintptr_t)row) & 15) == 0)) {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) { const double2 v = *reinterpret_cast<const double2 *>(row + k); tt[pass * 8 + k] = v.x; tt[pass * 8 + k + 1] = v.y; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) tt[pass * 8 + k] = (i < n && j0 + c8 + k < n) ? row[k] : 0.0;
+        }
+      }
+    }
+  };
+  /* acc += tile * x, x = xs[r][0..63] in LDS */
+  auto accumulate = [&](double (&acc)[TRSV_MAXR][2], const double (&tt)[16], const double (*xs)[TS]) {
+    if (mode == 1) {
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++)
+        if (r < nrhs) {
+#pragma unroll
+          for (int jj = 0; jj < 16; jj++) acc[r][0] = fma(tt[jj], xs[r][wave * 16 + jj], acc[r][0]);
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++)
+        if (r < nrhs) {
+#pragma unroll
+          for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[r][pass] = fma(tt[pass * 8 + k], xs[r][c8 + k], acc[r][pass]);
+        }
+    }
+  };
+  /* x_I = W (b_I - sum) for the block whose W is in sW; returns with srhs / s_part free again.  Publishes. */
+  auto solve_block = [&](unsigned I, const double (&acc)[TRSV_MAXR][2], const double (&bpre)[NQ], bool keep_local) {
+    const size_t i0 = (size_t)I * TS;
+    const int nbI = (int)((n - i0) < TS ? (n - i0) : TS);
+    if (mode == 1) {
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++) if (r < nrhs) s_part[r][wave][lane] = acc[r][0];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int e = q * 256 + tid, r = e / TS, c = e % TS;
+        if (e < nrhs * TS) {
+          const double sum = (s_part[r][0][c] + s_part[r][1][c]) + (s_part[r][2][c] + s_part[r][3][c]);
+          srhs[r][c] = (c < nbI) ? bpre[q] - sum : 0.0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < TRSV_MAXR; r++)
+        if (r < nrhs) {
+#pragma unroll
+          for (int pass = 0; pass < 2; pass++) {
+            double a = acc[r][pass];
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            const int row = pass * 32 + wave * 8 + rsub;
+            if ((lane & 7) == 0) srhs[r][row] = -a;
+          }
+        }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int e = q * 256 + tid, r = e / TS, c = e % TS;
+        if (e < nrhs * TS) srhs[r][c] = (c < nbI) ? bpre[q] + srhs[r][c] : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int r = wave; r < nrhs; r += 4) {
+      double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+      if (mode == 0) {
+#pragma unroll
+        for (int c = 0; c < TS; c += 4) {
+          p0 = fma(sW[lane][c], srhs[r][c], p0); p1 = fma(sW[lane][c + 1], srhs[r][c + 1], p1);
+          p2 = fma(sW[lane][c + 2], srhs[r][c + 2], p2); p3 = fma(sW[lane][c + 3], srhs[r][c + 3], p3);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < TS; c += 4) {
+          p0 = fma(sW[c][lane], srhs[r][c], p0); p1 = fma(sW[c + 1][lane], srhs[r][c + 1], p1);
+          p2 = fma(sW[c + 2][lane], srhs[r][c + 2], p2); p3 = fma(sW[c + 3][lane], srhs[r][c + 3], p3);
+        }
+      }
+      const double xv = (lane < nbI) ? (p0 + p1) + (p2 + p3) : 0.0;
+      if (keep_local) sxl[r][lane] = xv;
+      if (lane < nbI) {
+        unsigned long long *q = xq + 2 * ((size_t)r * npad + i0 + lane);
+        const unsigned long long tag = (unsigned long long)want << 32;
+        __hip_atomic_store(q, tag | (unsigned)__double2loint(xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, tag | (unsigned)__double2hiint(xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xout[r * ldb + i0 + lane] = xv;
+      }
+    }
+    __syncthreads();                                     /* sxl complete; srhs / s_part / sW free */
+  };
+
+  for (unsigned u = blockIdx.x; u < nunits; u += gridDim.x) {
+    const unsigned t0 = 2 * u, t1 = t0 + 1;
+    const bool two = t1 < nblk;
+    const unsigned I0 = (mode == 0) ? t0 : nblk - 1 - t0;
+    const unsigned I1 = two ? ((mode == 0) ? t1 : nblk - 1 - t1) : I0;
+    __syncthreads();                                     /* previous unit of this workgroup fully done with LDS */
+    for (int e = tid; e < TS * TS; e += 256) sW[e / TS][e % TS] = Dinv[(size_t)I0 * (TS * TS) + e];
+    /* everything the second block needs that does not depend on any x: its W, its right-hand side, the tile
+       that couples it to the first block -- in registers, off the dependent path */
+    double wpre[16], tloc[16], bpre0[NQ], bpre1[NQ];
+#pragma unroll
+    for (int q = 0; q < 16; q++) wpre[q] = two ? Dinv[(size_t)I1 * (TS * TS) + q * 256 + tid] : 0.0;
+    if (two) load_tile(tloc, I1, I0);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int e = q * 256 + tid, r = e / TS, c = e % TS;
+      const size_t i0 = (size_t)I0 * TS, i1 = (size_t)I1 * TS;
+      bpre0[q] = (e < nrhs * TS && i0 + c < n) ? b[r * ldb + i0 + c] : 0.0;
+      bpre1[q] = (two && e < nrhs * TS && i1 + c < n) ? b[r * ldb + i1 + c] : 0.0;
+    }
+    double acc0[TRSV_MAXR][2], acc1[TRSV_MAXR][2];
+#pragma unroll
+    for (int r = 0; r < TRSV_MAXR; r++) acc0[r][0] = acc0[r][1] = acc1[r][0] = acc1[r][1] = 0.0;
+    for (unsigned sstep = 0; sstep < t0; sstep++) {
+      const unsigned J = (mode == 0) ? sstep : nblk - 1 - sstep;
+      const size_t j0 = (size_t)J * TS;
+      double tt0[16], tt1[16];
+      load_tile(tt0, I0, J);                             /* independent of x_J: in flight while we wait for it */
+      if (two) load_tile(tt1, I1, J);
+      const int buf = sstep & 1;
+      for (int e = tid; e < nrhs * TS; e += 256) {
+        const int r = e / TS, c = e % TS;
+        double v = 0.0;
+        if (j0 + c < n) {
+          const unsigned long long *q = xq + 2 * ((size_t)r * npad + j0 + c);
+          unsigned long long w0, w1;
+          for (;;) {
+            w0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w0 >> 32) == want && (unsigned)(w1 >> 32) == want) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          v = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+        }
+        sx[buf][r][c] = v;
+      }
+      __syncthreads();
+      accumulate(acc0, tt0, sx[buf]);
+      if (two) accumulate(acc1, tt1, sx[buf]);
+    }
+    solve_block(I0, acc0, bpre0, two);
+    if (two) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) { const int e = q * 256 + tid; sW[e / TS][e % TS] = wpre[q]; }
+      accumulate(acc1, tloc, sxl);                       /* sxl complete: solve_block ended with a barrier */
+      solve_block(I1, acc1, bpre1, false);               /* begins with barriers that also cover the sW stores above */
+    }
+    if (t0 == nblk - 1 || (two && t1 == nblk - 1)) {     /* sweep complete: every other block was consumed above */
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(tf, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout,
                          size_t ldb, int nrhs, int mode, int unit, double *d_inv, int inv_ready)
 {
@@ -1111,6 +1313,16 @@ static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
   }
   static const bool no_df = getenv("GSL_SINTERP_NO_DATAFLOW_TRSV") && getenv("GSL_SINTERP_NO_DATAFLOW_TRSV")[0] == '1';
   if (use_inv && !no_df && ctx->sk_wgs > 0 && ctx->d_tf && ctx->tf_count >= nblk + 1 && ctx->d_xq) {
+    /* opt-in: measured slower (C3 init 33.1 -> 33.6 ms, C2 2.90 -> 3.00 ms): see the kernel's header */
+    static const bool pairs = getenv("GSL_SINTERP_TRSV_PAIRS") && getenv("GSL_SINTERP_TRSV_PAIRS")[0] == '1';
+    if (pairs && nblk >= 8) {
+      const size_t nunits = (nblk + 1) / 2;
+      const unsigned G2 = (unsigned)(nunits < (size_t)ctx->sk_wgs ? nunits : (size_t)ctx->sk_wgs);
+      hipLaunchKernelGGL(trsv_dataflow_pair_kernel, dim3(G2), dim3(256), 0, ctx->stream, T, ldt, n, (const double *)b, xout, ldb, nrhs,
+                         mode, (const double *)d_inv, ctx->d_tf, ctx->d_xq, (unsigned)nblk);
+      LAUNCH_CHECK(ctx);
+      return ST_SUCCESS;
+    }
     const unsigned G = (unsigned)(nblk < (size_t)ctx->sk_wgs ? nblk : (size_t)ctx->sk_wgs);
     hipLaunchKernelGGL(trsv_dataflow_kernel, dim3(G), dim3(256), 0, ctx->stream, T, ldt, n, (const double *)b, xout, ldb, nrhs, mode,
                        (const double *)d_inv, ctx->d_tf, ctx->d_xq, (unsigned)nblk);
