@@ -214,6 +214,28 @@ def run_config(env, name, steps, warmup):
     # ---- sanity of the result that was just produced (not timed)
     sample = d_s[: min(m_rank, 4096)].cpu().numpy()
     assert np.isfinite(sample).all(), "non-finite interpolated values"
+    if cfg["kind"] == "tps" and rank == 0:
+        # the reference's own route for this kernel class (gsl_linalg_LU_decomp + _svx, linalg/lu.c:59-201), forced, timed
+        # beside the default shifted-SPD route: 1 warm-up + 2 timed inits
+        os.environ["GSL_SINTERP_FORCE_LU"] = "1"
+        try:
+            lu_ms = []
+            for rep in range(3):
+                d_w.copy_(d_f)
+                ctx.timer_start()
+                st, route = ctx.rbf_solve(kind, eps, d_x.data_ptr(), n, dim, dim, d_phi.data_ptr(), n, d_w.data_ptr())
+                ms = ctx.timer_stop()
+                assert st == 0 and route == 3, (st, route)
+                if rep:
+                    lu_ms.append(ms)
+            extra["init_ms_reference_route_pivoted_lu"] = round(float(np.mean(lu_ms)), 3)
+        finally:
+            del os.environ["GSL_SINTERP_FORCE_LU"]
+        d_w.copy_(d_f)                                   # leave the default route's weights for the verification below
+        st, route = ctx.rbf_solve(kind, eps, d_x.data_ptr(), n, dim, dim, d_phi.data_ptr(), n, d_w.data_ptr())
+        assert st == 0
+    if cfg["kind"] == "tps" and world > 1:
+        dist.broadcast(d_w, 0)
     if cfg["kind"] != "bary":
         # the weights of the LAST timed step must interpolate the data: s(x_i) = f_i at a sample of the
         # centres (catches a step that ran fast because it computed garbage, e.g. a broken graph replay)

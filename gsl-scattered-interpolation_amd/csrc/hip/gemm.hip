@@ -392,17 +392,23 @@ __device__ __forceinline__ void decode_tile(const GemmArgs &g, unsigned tile, in
    quarter of a step's MFMAs (its fragments are already in registers) is issued AFTER the barrier and after the
    first fragment loads of the next step, so the matrix pipe stays fed through the rendezvous; the barrier also
    moves one quarter-step earlier relative to the DMA ring, which now runs three steps ahead instead of two. */
-template <int BM, int BN, int WM, int WN, int SS = 1, int ST = DM_STAGES, bool PIPE = false>
+/* BKN: the B operand is stored [k][n] (C -= A B, the N.N updates of the LU route) instead of [n][k].  Its LDS image per
+   step is then 16 k-rows of BN doubles, each row one linear 1-KiB DMA wave-instruction (BN = 128), rows pitched
+   BN + 16 doubles apart so that the (k = lane>>4, n = lane&15) fragment read -- 16 consecutive doubles per k-row,
+   k-rows 32 banks apart -- is conflict-free; no swizzle needed. */
+template <int BM, int BN, int WM, int WN, int SS = 1, int ST = DM_STAGES, bool PIPE = false, bool BKN = false>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 1)
 gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 {
   static_assert(ST == 3 || ST == 2, "ring depth");
   static_assert(!PIPE || (ST == 3 && SS == 1), "pipelined loop: three-deep ring of single steps");
+  static_assert(!BKN || BN == 128, "k-row = one 1-KiB DMA instruction");
   constexpr int WCOLS = BN / WN;                        /* waves along n */
   constexpr int NW = (BM / WM) * WCOLS;
   constexpr int NT = NW * 64;                           /* threads */
   constexpr int FM = WM / 16, FN = WN / 16;             /* MFMA fragments per wave */
-  constexpr int A_TILE = BM * GT_BK, B_TILE = BN * GT_BK;
+  constexpr int BPITCH = BN + 16;                       /* BKN: doubles between the k-rows of the B image */
+  constexpr int A_TILE = BM * GT_BK, B_TILE = BKN ? GT_BK * BPITCH : BN * GT_BK;
   constexpr int A_CH = BM / 8 / NW, B_CH = (BN / 8) / NW;
   static_assert(A_CH >= 1 && B_CH >= 1 && A_CH * 8 * NW == BM && B_CH * 8 * NW == BN, "tile / wave split");
   constexpr int PER_GROUP = SS * (A_CH + B_CH);         /* DMA wave-instructions a wave issues per group */
@@ -453,7 +459,7 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
       int koff[4];
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) koff[kk] = (((kk * 2 + (fq >> 1)) ^ sw) << 1) + (fq & 1);
-      const int arow = (wr * WM + fr) * GT_BK, brow = (wc * WN + fr) * GT_BK;
+      const int arow = (wr * WM + fr) * GT_BK, brow = BKN ? fq * BPITCH + wc * WN + fr : (wc * WN + fr) * GT_BK;
 
       const double *srcA[A_CH], *srcB[B_CH];
 #pragma unroll
@@ -464,7 +470,8 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 #pragma unroll
       for (int i = 0; i < B_CH; i++) {
         const int rr = (wave * B_CH + i) * 8 + (lane >> 3);
-        srcB[i] = g.B + (col0 + rr) * g.ldb + (((lane & 7) ^ ((rr >> 1) & 7)) << 1);
+        if constexpr (BKN) srcB[i] = g.B + (size_t)(wave * B_CH + i) * g.ldb + col0 + lane * 2;   /* chunk = k-row of the step */
+        else srcB[i] = g.B + (col0 + rr) * g.ldb + (((lane & 7) ^ ((rr >> 1) & 7)) << 1);
       }
       /* one group = SS sub-steps, each its own [rows][16] swizzled image (slot = stage * SS + sub-step) */
       auto issue = [&](int stage, size_t k0) {
@@ -473,7 +480,10 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 #pragma unroll
           for (int i = 0; i < A_CH; i++) dma16(srcA[i] + k0 + ss * GT_BK, sA + (stage * SS + ss) * A_TILE + (wave * A_CH + i) * 128);
 #pragma unroll
-          for (int i = 0; i < B_CH; i++) dma16(srcB[i] + k0 + ss * GT_BK, sB + (stage * SS + ss) * B_TILE + (wave * B_CH + i) * 128);
+          for (int i = 0; i < B_CH; i++) {
+            if constexpr (BKN) dma16(srcB[i] + (k0 + ss * GT_BK) * g.ldb, sB + (stage * SS + ss) * B_TILE + (wave * B_CH + i) * BPITCH);
+            else dma16(srcB[i] + k0 + ss * GT_BK, sB + (stage * SS + ss) * B_TILE + (wave * B_CH + i) * 128);
+          }
         }
       };
 
@@ -501,7 +511,7 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 #pragma unroll
           for (int i = 0; i < FM; i++) af[i] = a_base[i * 16 * GT_BK + koff[kk]];
 #pragma unroll
-          for (int j = 0; j < FN; j++) bf[j] = b_base[j * 16 * GT_BK + koff[kk]];
+          for (int j = 0; j < FN; j++) bf[j] = BKN ? b_base[kk * 4 * BPITCH + j * 16] : b_base[j * 16 * GT_BK + koff[kk]];
         };
         auto mma = [&](const double (&af)[FM], const double (&bf)[FN]) {
 #pragma unroll
@@ -584,7 +594,7 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 #pragma unroll
             for (int i = 0; i < FM; i++) af[i] = a_base[i * 16 * GT_BK + koff[kk]];
 #pragma unroll
-            for (int j = 0; j < FN; j++) bf[j] = b_base[j * 16 * GT_BK + koff[kk]];
+            for (int j = 0; j < FN; j++) bf[j] = BKN ? b_base[kk * 4 * BPITCH + j * 16] : b_base[j * 16 * GT_BK + koff[kk]];
 #pragma unroll
             for (int i = 0; i < FM; i++)
 #pragma unroll
@@ -943,6 +953,41 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
     hipLaunchKernelGGL(gemm_minus_dma_nt_kernel<2>, dim3(grid), dim3(256), lds, ctx->stream, g);
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
+  }
+  static const bool no_kn = getenv("GSL_SINTERP_NO_KN_STREAMK") && getenv("GSL_SINTERP_NO_KN_STREAMK")[0] == '1';
+  if (b_is_kn && full && !lower_only && !no_dma && !no_kn && ctx->sk_wgs > 0 && !ctx->use_lookahead && k >= 4 * GT_BK) {
+    /* C -= A B with B stored [k][n] (the N.N updates of the LU route): the stream-K DMA pipeline with a [k][n] B image */
+    StreamK x;
+    x.steps = (unsigned)(k / GT_BK);
+    x.partial = ctx->d_sk_partial; x.flags = ctx->d_sk_flags;
+    GemmArgs h = g;
+    unsigned tiles = grid;
+    bool big = false;
+    if ((m % 256) == 0) {
+      const unsigned t8 = (unsigned)(m / 256) * (unsigned)g.tiles_n;
+      if ((unsigned long long)t8 * x.steps >= 16ull * (unsigned)ctx->sk_wgs) { big = true; h.tiles_m = (int)(m / 256); tiles = t8; }
+    }
+    unsigned long long total64 = (unsigned long long)tiles * x.steps;
+    unsigned long long want = total64 / 16;
+    if (want < tiles) want = tiles;
+    if (want > (unsigned long long)ctx->sk_wgs) want = (unsigned long long)ctx->sk_wgs;
+    const unsigned G = (unsigned)(want ? want : 1);
+    x.dp_rounds = (tiles / G >= 2) ? tiles / G - 1 : 0;
+    total64 = (unsigned long long)(tiles - x.dp_rounds * G) * x.steps;
+    if (total64 < 0x7fffffffull) {
+      x.total = (unsigned)total64; x.base = x.total / G; x.rem = x.total % G;
+      if (big) {
+        const size_t lds = (size_t)DM_STAGES * (256 * GT_BK + GT_BK * (128 + 16)) * sizeof(double);      /* 150 KiB */
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<256, 128, 64, 64, 1, 3, true, true>, (int)lds); if (ast) return ast; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<256, 128, 64, 64, 1, 3, true, true>), dim3(G), dim3(512), lds, ctx->stream, h, x);
+      } else {
+        const size_t lds = (size_t)DM_STAGES * (128 * GT_BK + GT_BK * (128 + 16)) * sizeof(double);
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<128, 128, 64, 64, 1, 3, true, true>, (int)lds); if (ast) return ast; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<128, 128, 64, 64, 1, 3, true, true>), dim3(G), dim3(256), lds, ctx->stream, h, x);
+      }
+      LAUNCH_CHECK(ctx);
+      return ST_SUCCESS;
+    }
   }
   if (b_is_kn) {
     if (full) hipLaunchKernelGGL((gemm_minus_kernel<1, true>), dim3(grid), dim3(256), 0, ctx->stream, g);

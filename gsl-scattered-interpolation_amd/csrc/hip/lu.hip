@@ -568,7 +568,9 @@ extern "C" int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, dou
   if (h_signum) *h_signum = 1;
   if (n == 0) return ST_SUCCESS;
   int replayed = 0;
-  int st = sinterp_graph_try_launch(ctx, 1, n, lda, d_a, d_perm, &replayed);
+  int st = sinterp_streamk_prepare(ctx);               /* the N.N updates run on the stream-K kernel (buffers: outside capture) */
+  if (st) return st;
+  st = sinterp_graph_try_launch(ctx, 1, n, lda, d_a, d_perm, &replayed);
   if (st) return st;
   if (!replayed) {
     hipStream_t saved;

@@ -89,7 +89,7 @@ def test_hilbert_known_answers(pkg, n):
     assert ok(d_x.cpu().numpy(), spec["lu_eps_mult"] * EPS if "lu_eps_mult" in spec else spec["lu_abs_tol"])
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 33, 100, 255, 1024, 2000])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 33, 100, 255, 1024, 2000, 2048])
 def test_lu_decomp_and_solve(pkg, orc, n):
     rng = np.random.default_rng(n)
     a = rng.standard_normal((n, n))
@@ -133,6 +133,8 @@ def test_lu_singular_reports_edom(pkg):
     (2048, 2048, 2048, 0, 1), (2048, 1024, 1536, 0, 0),  # stream-K, 8-wave: several contributors per tile
     (4224, 2048, 256, 0, 0), (4224, 2048, 192, 0, 1),    # stream-K, 128x128 tiles (>= 512 tiles, rows not a multiple of 256)
     (3072, 256, 256, 0, 1), (1920, 128, 128, 0, 1),      # stream-K, 64x64 tiles: panel updates of the recursion's low levels
+    (2048, 2048, 2048, 1, 0), (1024, 1024, 512, 1, 0), (2304, 384, 1024, 1, 0), (4224, 2048, 256, 1, 0),   # B stored [k][n] (LU's
+    (1152, 128, 64, 1, 0), (256, 256, 4096, 1, 0),                                                         # N.N updates): stream-K, [k][n] image
 ])
 def test_gemm_building_block(pkg, m, n, k, kn, lower):
     """C -= A op(B) on fp64 MFMA vs numpy, for every kernel variant behind gsl_sinterp_hip_gemm_minus."""

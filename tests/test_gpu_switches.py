@@ -18,7 +18,7 @@ BARY = ["tests/test_gpu_bary.py"]
 
 CASES = [
     ("GSL_SINTERP_NO_GRAPH", LINALG), ("GSL_SINTERP_NO_GRAPH", RBF_INIT),
-    ("GSL_SINTERP_NO_STREAMK", LINALG), ("GSL_SINTERP_NO_HYBRID_SK", LINALG), ("GSL_SINTERP_NO_GEMM8", LINALG), ("GSL_SINTERP_NO_GEMM64", LINALG), ("GSL_SINTERP_NO_GEMM_GROUP", LINALG), ("GSL_SINTERP_NO_GEMM_PIPE", LINALG), ("GSL_SINTERP_SUPERTILE", LINALG),
+    ("GSL_SINTERP_NO_STREAMK", LINALG), ("GSL_SINTERP_NO_HYBRID_SK", LINALG), ("GSL_SINTERP_NO_GEMM8", LINALG), ("GSL_SINTERP_NO_GEMM64", LINALG), ("GSL_SINTERP_NO_GEMM_GROUP", LINALG), ("GSL_SINTERP_NO_GEMM_PIPE", LINALG), ("GSL_SINTERP_NO_KN_STREAMK", LINALG), ("GSL_SINTERP_SUPERTILE", LINALG),
     ("GSL_SINTERP_NO_DMA_GEMM", LINALG), ("GSL_SINTERP_NO_PANEL128", LINALG), ("GSL_SINTERP_NO_PANEL128", RBF_INIT),
     ("GSL_SINTERP_NO_DATAFLOW_TRSV", LINALG), ("GSL_SINTERP_NO_DATAFLOW_TRSV", RBF_INIT), ("GSL_SINTERP_TRSV_PAIRS", LINALG),
     ("GSL_SINTERP_LOOKAHEAD", LINALG),
