@@ -311,8 +311,18 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
     const bool is_row = lane < CB;
     const int c = lane - CB;
     double a[CB];
+    {
+      /* branch-free: every lane reads a whole row of the block (lanes 32..63 the row of lane - 32, discarded) as 16
+         unconditional ds_read_b128, then selects; a per-entry `k <= lane ? D[..] : 0` compiles to 32 exec-masked
+         branches with a full LDS round trip each (~3k cycles per block, measured as the gap between the column
+         stamps and the block total) */
+      const double *rowp = D + (lane & (CB - 1)) * PQ;
+      double v[CB];
 #pragma unroll
-    for (int k = 0; k < CB; k++) a[k] = is_row ? ((k <= lane) ? D[lane * PQ + k] : 0.0) : ((k == c) ? 1.0 : 0.0);
+      for (int k = 0; k < CB; k += 2) { const double2 t = *reinterpret_cast<const double2 *>(rowp + k); v[k] = t.x; v[k + 1] = t.y; }
+#pragma unroll
+      for (int k = 0; k < CB; k++) a[k] = is_row ? ((k <= lane) ? v[k] : 0.0) : ((k == c) ? 1.0 : 0.0);
+    }
     double *colp = is_row ? D + lane * PQ : Dv + jb * PBLK + c;   /* entry J of this lane's vector: colp[J * cstride] */
     const int cstride = is_row ? 1 : PQ;
     int badcol = 0;
