@@ -445,7 +445,7 @@ def cpu_baseline(cfg, n, dim, m_total):
     f = orc.synth_response(x)
     # --- factorisation + solves at N in {2048, 4096}, reference order, one thread; N^3 extrapolation
     fact = {}
-    for ns in (2048, 4096):
+    for ns in ((2048, 4096) if n >= 2048 else (n,)):      # a configuration below 2048 centres is measured whole
         if ns > n:
             continue
         xs, fs = np.ascontiguousarray(x[:ns]), np.ascontiguousarray(f[:ns])
