@@ -145,6 +145,57 @@ __device__ __forceinline__ double violation(double c0, double c1)
   return worst;
 }
 
+/* Division-free containment test with a certificate (round 2).  The walk spends most of its VALU time in
+   the two IEEE fp64 divides of solve_node (~35 instructions each, two per test, ~60 tests per target).  A test only
+   needs the DECISION inside_unit(c0, c1); the quotients themselves are needed in the final leaf alone.  Here
+   the coordinates are formed with reciprocals (v_rcp_f64 + two Newton steps, the seed + refinement of the
+   compiler's own fdiv expansion without its scaling / fix-up: relative error eps <= 2^-50 for any seed better than
+   2^-13) from numerators computed by the very operations of the exact path, and the decision is accepted only
+   when it provably equals the exact one (below 8e-15 stands for eps + a few roundings, generously):
+       exact:   c1 = fl(n1 / u11),  n0 = fl(t0 - fl(u01 c1)),  c0 = fl(n0 / u00),  tot = fl(c0 + c1)
+       approx:  c1a = n1 r11,       n0a = fl(t0 - fl(u01 c1a)), c0a = n0a r00,     ta  = fl(c0a + c1a)
+       |c1a - c1| <= 8e-15 |c1a|,   |c0a - c0| <= 8e-15 (|u01 c1a| + |t0|) / |u00| + 8e-15 |c0a|  =: e0,
+       |ta - tot| <= e0 + 8e-15 |c1a| + 3e-16 (|c0a| + |c1a|)
+   so with  B = 1e-12 (1 + E0 + |c1a|),  E0 = (|u01 c1a| + |t0|) |r00|  (>= |c0a|): more than 100x those bounds,
+       every value in [B, 1 - B]           => the exact test says inside,
+       some value <= -B or >= 1 + B        => the exact test says outside,
+   anything else (a target within ~1e-12 of an edge of this node, a sliver with a huge E0, inf / NaN from a
+   denormal pivot: every comparison below is false on NaN) is UNDECIDED and the caller repeats the node with the
+   exact arithmetic.  Returns +1 inside, -1 outside, 0 undecided. */
+__device__ __forceinline__ double rcp_newton(double d)
+{
+  double y = __builtin_amdgcn_rcp(d);                /* v_rcp_f64: a ~2^-23-accurate seed */
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);                               /* second step: the bound below must not hinge on the seed's accuracy */
+  return fma(y, e, y);
+}
+
+__device__ __forceinline__ int classify_fast(const NodeRec &r, double y0, double y1, double s0, double s1)
+{
+  const double b0 = (y0 - r.x0) * s0;
+  const double b1 = (y1 - r.x1) * s1;
+  const bool sw = META_SWAPPED(r.meta);
+  const double t0 = sw ? b1 : b0;
+  double t1 = sw ? b0 : b1;
+  t1 -= r.l10 * t0;                                  /* n1: the exact path's numerator, same operations */
+  const double r11 = rcp_newton(r.u11), r00 = rcp_newton(r.u00);
+  const double c1a = t1 * r11;
+  const double p = r.u01 * c1a;
+  const double c0a = (t0 - p) * r00;
+  const double E0 = (fabs(p) + fabs(t0)) * fabs(r00);
+  const double B = 1e-12 * ((1.0 + E0) + fabs(c1a));
+  const double ta = c0a + c1a;
+  const double lo = fmin(fmin(c0a, c1a), ta), hi = fmax(fmax(c0a, c1a), ta);
+  /* fmin / fmax drop NaNs: test the three values for NaN through B and E0 as well (NaN anywhere -> E0 or B NaN
+     or the sums NaN); the explicit self-comparisons keep the certificate independent of that reasoning */
+  const bool finite = (c0a == c0a) && (c1a == c1a) && (B == B) && (B < 1e300);
+  if (!finite) return 0;
+  if (lo >= B && hi <= 1.0 - B) return 1;
+  if (lo <= -B || hi >= 1.0 + B) return -1;
+  return 0;
+}
+
 __device__ __forceinline__ NodeRec load_rec(const NodeRec *__restrict__ rec, int k)
 {
   /* four 16-byte loads of one aligned 64-byte line */
@@ -244,6 +295,7 @@ jump_build_kernel(int n_nodes, const NodeRec *__restrict__ rec, double s0, doubl
   jump[cell] = node;
 }
 
+template <bool FAST>
 __global__ void __launch_bounds__(256)
 bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, double s0, double s1,
                  const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
@@ -294,6 +346,9 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
       }
     }
     int guard = 0;
+    /* (c0, c1) hold the reference's persistent coordinates (accel->coords) unless the last descent was decided by
+       the division-free test; then they are the exact coordinates of `cur`, recomputed on demand */
+    bool have_exact = true;
     while (META_TYPE(cur.meta) != 0 && guard++ < 4096) { /* depth is O(log N); bound the walk */
       const int nc = META_NCHILD(cur.meta);
       int best = 0, next = -1;
@@ -308,6 +363,29 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
                  v2 = nc > 2 && ch2 > 0 && ch2 < n_nodes;
       const NodeRec cr0 = load_rec(rec, v0 ? ch0 : 0), cr1 = load_rec(rec, v1 ? ch1 : 0), cr2 = load_rec(rec, v2 ? ch2 : 0);
       /* (named records, not an array: an indexed array of structs ends up in scratch memory) */
+      if (FAST) {
+        /* children in the reference's order; an invalid or singular child is never a hit (certainly "outside");
+           the first certainly-inside child after only certainly-outside ones is the reference's choice */
+        bool decided = true;
+#define BARY_FAST_CHILD(I, CR, VALID, CH)                                                            \
+        if ((I) < nc && next < 0 && decided) {                                                        \
+          if ((VALID) && !META_SINGULAR((CR).meta)) {                                                 \
+            const int cls = classify_fast(CR, y0, y1, s0, s1);                                        \
+            if (cls > 0) { next = (CH); nrec = (CR); }                                                \
+            else if (cls == 0) decided = false;                                                       \
+          }                                                                                           \
+        }
+        BARY_FAST_CHILD(0, cr0, v0, ch0)
+        BARY_FAST_CHILD(1, cr1, v1, ch1)
+        BARY_FAST_CHILD(2, cr2, v2, ch2)
+#undef BARY_FAST_CHILD
+        if (decided && next >= 0) { node = next; cur = nrec; have_exact = false; continue; }
+        /* undecided child, or no child certainly contains the target (the reference's least-violation fallback
+           compares exact coordinates): repeat this node with the exact arithmetic */
+        next = -1;
+        nrec = cur;
+        if (!have_exact) { solve_node(cur, y0, y1, s0, s1, c0, c1); have_exact = true; }   /* cur was a hit: not singular */
+      }
 #define BARY_TEST_CHILD(I, CR, VALID, CH)                                                            \
       if ((I) < nc && next < 0) {                                                                     \
         bool hit = false;                                                                             \
@@ -448,11 +526,19 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   }
   size_t blocks = (m + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(bary_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
-                     (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1],
-                     sorted ? (const double *)srt.ys : d_targets, m, sorted ? (size_t)2 : ttda, sorted ? srt.vs : d_values,
-                     sorted ? (d_leaf ? srt.ls : (int *)NULL) : d_leaf, d_count, (const int *)NULL, (const int *)d_jump, G,
-                     d_jbox);
+  static const bool no_fast = getenv("GSL_SINTERP_NO_FASTDIV") && getenv("GSL_SINTERP_NO_FASTDIV")[0] == '1';
+  if (no_fast)
+    hipLaunchKernelGGL(bary_eval_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
+                       (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1],
+                       sorted ? (const double *)srt.ys : d_targets, m, sorted ? (size_t)2 : ttda, sorted ? srt.vs : d_values,
+                       sorted ? (d_leaf ? srt.ls : (int *)NULL) : d_leaf, d_count, (const int *)NULL, (const int *)d_jump, G,
+                       d_jbox);
+  else
+    hipLaunchKernelGGL(bary_eval_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
+                       (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1],
+                       sorted ? (const double *)srt.ys : d_targets, m, sorted ? (size_t)2 : ttda, sorted ? srt.vs : d_values,
+                       sorted ? (d_leaf ? srt.ls : (int *)NULL) : d_leaf, d_count, (const int *)NULL, (const int *)d_jump, G,
+                       d_jbox);
   LAUNCH_CHECK(ctx);
   if (sorted) {
     int st = sinterp_unsort(ctx, &srt, m, d_values, d_leaf);

@@ -250,3 +250,30 @@ def test_sliver_geometry_stays_bitexact(pkg, orc, cloud):
     assert st == 0
     assert np.array_equal(leaf, oleaf)
     assert np.array_equal(bits(vals), bits(ovals))
+
+
+def test_division_free_containment_margin(pkg, orc):
+    """The walk decides containment with reciprocals and an error certificate and repeats a node with the exact
+    IEEE arithmetic when the certificate fails (bary.hip: classify_fast).  Targets placed ON edges and vertices
+    of the triangulation and then moved off them by 1e-16 ... 1e-9 of the data's extent straddle exactly that
+    margin: every one must still land in the oracle's leaf with the oracle's bits."""
+    n = 6000
+    rng = np.random.default_rng(23)
+    x = orc.synth_centres(n, 2) * np.array([3.0, 0.5]) + np.array([-7.0, 11.0])
+    f = orc.synth_response(x)
+    t, o = build_pair(pkg, orc, x)
+    d = t.device_alloc(0)
+    assert d.set_response(f) == 0
+    pairs = rng.integers(0, n, size=(4000, 2))
+    lam = rng.random((4000, 1))
+    on_segments = lam * x[pairs[:, 0]] + (1.0 - lam) * x[pairs[:, 1]]
+    base = np.concatenate([x, on_segments])
+    ys = [base]
+    for mag in (1e-16, 1e-15, 1e-14, 1e-13, 3e-13, 1e-12, 3e-12, 1e-11, 1e-10, 1e-9):
+        ys.append(base + mag * 3.0 * rng.standard_normal(base.shape))
+    y = np.ascontiguousarray(np.concatenate(ys))
+    st, vals, leaf = d.eval_many(y)
+    ovals, oleaf = o.eval_many(x, f, y)
+    assert st == 0
+    assert np.array_equal(leaf, oleaf)
+    assert np.array_equal(bits(vals), bits(ovals))
