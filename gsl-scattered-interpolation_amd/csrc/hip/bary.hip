@@ -295,13 +295,312 @@ jump_build_kernel(int n_nodes, const NodeRec *__restrict__ rec, double s0, doubl
   jump[cell] = node;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Affine walk records (round 2).  Barycentric coordinates are affine in the target, so the DECISION of a
+   containment test needs no triangular solve: per node the inverse of the standardised edge matrix (scale and row
+   swap folded in) is formed once per batch from the node's LU record, and a test is
+       d = y - x,   c0 ~ m00 d0 + m01 d1,   c1 ~ m10 d0 + m11 d1          (6 flops instead of ~90 instructions)
+   The walk kernel below accepts such a decision only under a certificate that it equals the decision of the exact
+   path (solve_node + inside_unit, the reference's arithmetic); a target that meets an uncertified test anywhere is
+   queued and walked by bary_eval_kernel from the start.  Located leaves get their coordinates from solve_node, so
+   the values and leaves of both kernels are the reference's, bit for bit.
+
+   Certificate.  With u = 2^-53, (a, b) = the target components feeding (t0, t1) of solve_node, and
+       Q1 = (s_b |d_b| + |l10| s_a |d_a|) / |u11|,     Q0 = (s_a |d_a| + |u01| Q1) / |u00|,    q = Q0 + Q1,
+   a standard forward analysis of solve_node's ten operations (no underflow, see below) gives for its computed
+   coordinates against the real-arithmetic ones c*:  |c1 - c1*| <= 4u Q1,  |c0 - c0*| <= 7u Q0,  |tot - tot*| <= 12u q;
+   the matrix entries are formed with <= 5u relative error against the same absolute-value expressions, so the
+   affine values obey |c1a - c1*| <= 8u Q1, |c0a - c0*| <= 8u Q0, |ta - tot*| <= 9u q.  Hence all three differ from
+   the exact path's by less than 21u q, and q <= alpha (|d0| + |d1|) with the per-node constant alpha stored (as a
+   float rounded up, times 2^-47 = 64u) in the record.  With B = bound (|d0| + |d1|) + 2^-800 >= 64u q:
+       min(c0a, c1a, ta) >= B  and  max(...) <= 1 - B    =>  inside_unit(exact) is true,
+       min(...) <= -B  or  max(...) >= 1 + B  (B < 2^400) =>  inside_unit(exact) is false,
+   otherwise undecided.  Underflow / overflow: a node gets bound = +inf (never certified) when it is singular or
+   when the product of max(1, |v|, 1/|v|) over its LU entries and the scales exceeds 2^200; below that, underflows
+   in the exact path perturb its results by < 2^-860 (covered by the 2^-800 floor) and B < 2^400 keeps every
+   intermediate below 2^650.  NaN / inf anywhere makes every comparison false: undecided. */
+struct __attribute__((aligned(64))) WalkRec {
+  double x0, x1;             /* NodeRec's origin */
+  double m00, m01, m10, m11;
+  float bound;               /* 64u alpha, rounded up; +inf: never certified */
+  int child[3];              /* children the reference would test AND could hit (0: none); child[0] = -1: leaf */
+};
+static_assert(sizeof(WalkRec) == 64, "walk record size");
+#define WALK_FLOOR 0x1p-800
+
+__global__ void __launch_bounds__(256)
+walk_pack_kernel(int n_nodes, const NodeRec *__restrict__ rec, double s0, double s1, WalkRec *__restrict__ wrec)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_nodes) return;
+  const NodeRec r = rec[k];
+  const bool sw = META_SWAPPED(r.meta);
+  const double sa = sw ? s1 : s0, sb = sw ? s0 : s1;
+  const double m1a = -(r.l10 * sa) / r.u11, m1b = sb / r.u11;
+  const double m0a = (sa - r.u01 * m1a) / r.u00, m0b = -(r.u01 * m1b) / r.u00;
+  const double A1a = fabs(r.l10) * sa / fabs(r.u11), A1b = sb / fabs(r.u11);
+  const double A0a = (sa + fabs(r.u01) * A1a) / fabs(r.u00), A0b = fabs(r.u01) * A1b / fabs(r.u00);
+  const double alpha = fmax(A0a + A1a, A0b + A1b) * (0x1p-47 * (1.0 + 0x1p-10));
+  double g = 1.0;
+  const double v[6] = {r.l10, r.u01, r.u11, r.u00, sa, sb};
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const double a = fabs(v[i]);
+    g *= fmax(1.0, a);
+    if (i >= 2) g *= fmax(1.0, 1.0 / a);
+  }
+  const bool ok = !META_SINGULAR(r.meta) && sa > 0.0 && sb > 0.0 && g <= 0x1p200 && alpha < 1e30 &&
+                  m0a == m0a && m0b == m0b && m1a == m1a && m1b == m1b;             /* NaN in g or alpha: false */
+  WalkRec w;
+  w.x0 = r.x0; w.x1 = r.x1;
+  w.m00 = sw ? m0b : m0a; w.m01 = sw ? m0a : m0b;       /* back to the (d0, d1) order */
+  w.m10 = sw ? m1b : m1a; w.m11 = sw ? m1a : m1b;
+  w.bound = ok ? fmaxf((float)alpha * (1.0f + 0x1p-20f), 1.1754944e-38f) : INFINITY;
+  if (META_TYPE(r.meta) == 0) { w.child[0] = -1; w.child[1] = 0; w.child[2] = 0; }
+  else {
+    const int nc = META_NCHILD(r.meta);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int ch = r.child[i];
+      w.child[i] = (i < nc && ch > 0 && ch < n_nodes) ? ch : 0;
+    }
+  }
+  wrec[k] = w;
+}
+
+__device__ __forceinline__ WalkRec load_wrec(const WalkRec *__restrict__ wrec, int k)
+{
+  union { int4 q[4]; WalkRec r; } u;
+  const int4 *p = (const int4 *)(wrec + k);
+  u.q[0] = p[0]; u.q[1] = p[1]; u.q[2] = p[2]; u.q[3] = p[3];
+  return u.r;
+}
+
+/* in: the exact test certainly says inside; out: certainly outside; neither: undecided.  Branch-free: the walk's
+   step evaluates all three children and combines the flags as lane masks. */
+__device__ __forceinline__ void classify_affine(const WalkRec &w, double y0, double y1, bool &in, bool &out)
+{
+  const double d0 = y0 - w.x0, d1 = y1 - w.x1;
+  const double c0 = fma(w.m01, d1, w.m00 * d0);
+  const double c1 = fma(w.m11, d1, w.m10 * d0);
+  const double t = c0 + c1;
+  const double B = (double)w.bound * (fabs(d0) + fabs(d1)) + WALK_FLOOR;
+  const double lo = fmin(fmin(c0, c1), t), hi = fmax(fmax(c0, c1), t);
+  in = (lo >= B) & (hi <= 1.0 - B);
+  out = ((lo <= -B) | (hi >= 1.0 + B)) & (B < 0x1p400);
+}
+
+#ifdef SINTERP_DIAG_PROF
+/* developer build (make prof, tools/walk_stats.py): wave-iterations and active lanes of the three phases of
+   bary_walk_kernel: [0] step iterations, [1] lanes stepping, [2] start phases, [3] lanes started, [4] finish phases,
+   [5] lanes finished */
+__device__ unsigned long long g_walk_stats[40];
+extern "C" int gsl_sinterp_hip_debug_walk_stats(unsigned long long *out, int reset)
+{
+  int st = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_stats), sizeof(unsigned long long) * 40);
+  if (reset) { unsigned long long z[40] = {0}; st |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stats), z, sizeof z); }
+  return st;
+}
+#endif
+
+/* The walk lengths of the targets of one wave differ widely (C5: 40 % of the targets start in their leaf, the mean
+   is 6.5 steps, yet the longest of 64 neighbours averages 24): a wave that keeps a target per lane until all 64 are
+   done runs at 27 % lane utilisation.  Here a lane is a worker: when enough lanes of a wave are idle the wave draws
+   that many new targets from a global counter (consecutive indices of the cell-sorted order, so the wave's lanes
+   still walk neighbouring parts of the DAG), and the three phases -- start (jump table + start node), step (test the
+   children), finish (exact coordinates in the leaf, store) -- each run for the lanes in that state under a
+   wave-uniform condition; start and finish are batched (>= WALK_BATCH lanes, or nothing else to do). */
+#define WALK_BATCH 16
+#define WALK_CHUNK 256
+/* Gathers.  A lane that reads its own 64-byte record with four 16-byte loads costs the CU's L1 four cache-line
+   look-ups per record, and the L1 serves about one line per clock: with 64 lanes on 64 different lines the step's
+   twelve loads took ~770 clocks per wave and bounded the kernel (measured: the time did not move with occupancy 3..7
+   nor with half the VALU work).  Instead the four lanes of a quad fetch ONE record per instruction, 16 bytes each
+   (one line per quad), straight into LDS (global_load_lds_dwordx4, lane l -> base + 16 l), four instructions per
+   child = the records of the quad's four lanes; a lane then reads its record back with four ds_read_b128.  The
+   per-instruction LDS images are 1040 bytes apart so that the 16 lanes of a read pass hit 64 different banks. */
+#define WALK_IMG 1040
+#define WALK_WAVE_LDS (12 * WALK_IMG)
+
+template <int J>
+__device__ __forceinline__ int quad_bcast(int v)          /* lane J of the quad -> all four */
+{
+  return __builtin_amdgcn_update_dpp(0, v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ void dma_part(const WalkRec *wrec, int idx, int part, char *img)
+{
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)(wrec + idx) + part * 16),
+                                   (__attribute__((address_space(3))) void *)img, 16, 0, 0);
+}
+
+__device__ __forceinline__ WalkRec lds_rec(const char *p)
+{
+  union { int4 q[4]; WalkRec r; } u;
+  const int4 *q = (const int4 *)p;
+  u.q[0] = q[0]; u.q[1] = q[1]; u.q[2] = q[2]; u.q[3] = q[3];
+  return u.r;
+}
+__global__ void __launch_bounds__(256)
+bary_walk_kernel(int n_nodes, const NodeRec *__restrict__ rec, const WalkRec *__restrict__ wrec,
+                 const LeafRec *__restrict__ tab, double s0, double s1, const double *__restrict__ targets, size_t m,
+                 size_t ttda, double *__restrict__ values, int *__restrict__ leaf_out, const int *__restrict__ jump, int G,
+                 const unsigned long long *__restrict__ box, unsigned *__restrict__ todo_count, int *__restrict__ todo,
+                 unsigned long long *__restrict__ next_target, int batch)
+{
+  double jlo0 = 0, jlo1 = 0, jw0 = 0, jw1 = 0;
+  if (jump) {
+    jlo0 = key_to_double(box[0]); jlo1 = key_to_double(box[2]);
+    jw0 = (key_to_double(box[1]) - jlo0) / G; jw1 = (key_to_double(box[3]) - jlo1) / G;
+  }
+  __shared__ __attribute__((aligned(16))) char lds[4 * WALK_WAVE_LDS];
+  char *const img = lds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * WALK_WAVE_LDS;
+  const int lane = threadIdx.x & 63;
+  enum { IDLE = 0, WALK = 1, FINISH = 2 };
+  int state = IDLE, node = 0, ch0 = 0, ch1 = 0, ch2 = 0, guard = 0;
+  size_t k = 0;
+  double y0 = 0, y1 = 0;
+  bool exhausted = false;                                  /* wave-uniform */
+  unsigned long long cbeg = 0, cend = 0;                   /* wave-uniform: what is left of the wave's current chunk */
+#ifdef SINTERP_DIAG_PROF
+  unsigned long long it_step = 0, it_start = 0, it_finish = 0, lanes_step = 0, lanes_start = 0, lanes_finish = 0;
+#endif
+  for (;;) {
+    const unsigned long long walking = __ballot(state == WALK);
+    /* ---- finish: exact coordinates in the located leaf (interp_point recomputes them: the reference's arithmetic) */
+    const unsigned long long finishing = __ballot(state == FINISH);
+    if (finishing && (__popcll(finishing) >= batch || !walking)) {
+#ifdef SINTERP_DIAG_PROF
+      it_finish++; lanes_finish += __popcll(finishing);
+#endif
+      if (state == FINISH) {
+        const NodeRec cur = load_rec(rec, node);
+        double c0, c1;
+        solve_node(cur, y0, y1, s0, s1, c0, c1);
+        const LeafRec lr = tab[node];
+        double tot = 0, interp = 0;
+        tot += c0;
+        if (lr.mask & 1) interp += c0 * lr.f[0];
+        tot += c1;
+        if (lr.mask & 2) interp += c1 * lr.f[1];
+        if (lr.mask & 4) interp += (1 - tot) * lr.f[2];
+        values[k] = interp;
+        if (leaf_out) leaf_out[k] = node;
+        state = IDLE;
+      }
+    }
+    /* ---- start: new targets for the idle lanes */
+    const unsigned long long idle = __ballot(state == IDLE);
+    if (!exhausted && idle && (__popcll(idle) >= batch || !walking)) {
+      unsigned nidle = (unsigned)__popcll(idle);
+      if (cbeg == cend) {
+        /* one atomic per WALK_CHUNK targets (one per refill serialises ~500k same-address atomics: 7 ms) */
+        unsigned long long got = 0;
+        if ((threadIdx.x & 63) == 0) got = atomicAdd(next_target, (unsigned long long)WALK_CHUNK);
+        got = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) |
+              (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)got);
+        cbeg = got < m ? got : m;
+        cend = got + WALK_CHUNK < m ? got + WALK_CHUNK : m;
+      }
+      const unsigned long long base = cbeg;
+      if (nidle > cend - cbeg) nidle = (unsigned)(cend - cbeg);
+      cbeg += nidle;
+      exhausted = cbeg >= m;                               /* the chunk that ended at m was the last one */
+#ifdef SINTERP_DIAG_PROF
+      it_start++; lanes_start += nidle;
+#endif
+      if (state == IDLE) {
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+        k = base + rank;
+        if (rank < nidle) {
+          y0 = targets[k * ttda]; y1 = targets[k * ttda + 1];
+          node = 0;
+          if (jump && jw0 > 0.0 && jw1 > 0.0 && y0 == y0 && y1 == y1) {       /* same start as bary_eval_kernel */
+            int ix = (int)((y0 - jlo0) / jw0), iy = (int)((y1 - jlo1) / jw1);
+            ix = ix < 0 ? 0 : (ix >= G ? G - 1 : ix);
+            iy = iy < 0 ? 0 : (iy >= G ? G - 1 : iy);
+            const bool in_cell = y0 >= jlo0 + jw0 * ix - JUMP_SLACK * jw0 && y0 <= jlo0 + jw0 * (ix + 1) + JUMP_SLACK * jw0 &&
+                                 y1 >= jlo1 + jw1 * iy - JUMP_SLACK * jw1 && y1 <= jlo1 + jw1 * (iy + 1) + JUMP_SLACK * jw1;
+            const int start = in_cell ? jump[iy * G + ix] : 0;
+            if (start > 0 && start < n_nodes) node = start;
+          }
+          const WalkRec cw = load_wrec(wrec, node);
+          guard = 0;
+          /* the start node (a jump-table node or the caging simplex) must certainly contain the target */
+          bool in, out;
+          classify_affine(cw, y0, y1, in, out);
+          if (in) {
+            ch0 = cw.child[0]; ch1 = cw.child[1]; ch2 = cw.child[2];
+            state = ch0 == -1 ? FINISH : WALK;
+          } else {
+            todo[atomicAdd(todo_count, 1u)] = (int)k;                           /* the exact walk takes it */
+          }
+        }
+      }
+    }
+    /* ---- step: the reference's order -- the first child that certainly contains the target, all earlier ones
+       certainly not; anything else (also: no child certainly contains it, the reference's least-violation
+       fallback) goes to the exact walk */
+    if (__ballot(state == WALK)) {
+#ifdef SINTERP_DIAG_PROF
+      it_step++; lanes_step += __popcll(__ballot(state == WALK));
+#endif
+      {
+        /* all 64 lanes: instruction (child c, j) fetches the child-c record of the quad's lane j */
+        const int e0 = state == WALK ? ch0 : 0, e1 = state == WALK ? ch1 : 0, e2 = state == WALK ? ch2 : 0;
+        const int part = lane & 3;
+#define WALK_FETCH(C, E, J) { const int idx = quad_bcast<J>(E); if (idx > 0) dma_part(wrec, idx, part, img + ((C) * 4 + (J)) * WALK_IMG); }
+        WALK_FETCH(0, e0, 0) WALK_FETCH(0, e0, 1) WALK_FETCH(0, e0, 2) WALK_FETCH(0, e0, 3)
+        WALK_FETCH(1, e1, 0) WALK_FETCH(1, e1, 1) WALK_FETCH(1, e1, 2) WALK_FETCH(1, e1, 3)
+        WALK_FETCH(2, e2, 0) WALK_FETCH(2, e2, 1) WALK_FETCH(2, e2, 2) WALK_FETCH(2, e2, 3)
+#undef WALK_FETCH
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (state == WALK) {
+        const char *mine = img + (lane & 3) * WALK_IMG + (lane & ~3) * 16;
+        const WalkRec w0 = lds_rec(mine), w1 = lds_rec(mine + 4 * WALK_IMG), w2 = lds_rec(mine + 8 * WALK_IMG);
+        bool in0, out0, in1, out1, in2, out2;
+        classify_affine(w0, y0, y1, in0, out0);
+        classify_affine(w1, y0, y1, in1, out1);
+        classify_affine(w2, y0, y1, in2, out2);
+        const bool v0 = ch0 > 0, v1 = ch1 > 0, v2 = ch2 > 0;
+        const bool hit0 = v0 & in0, pass0 = !v0 | out0;                 /* pass: certainly not a hit */
+        const bool hit1 = pass0 & v1 & in1, pass1 = pass0 & (!v1 | out1);
+        const bool hit2 = pass1 & v2 & in2;
+        const int next = hit0 ? ch0 : (hit1 ? ch1 : ch2);
+        const int n0 = hit0 ? w0.child[0] : (hit1 ? w1.child[0] : w2.child[0]);
+        const int n1 = hit0 ? w0.child[1] : (hit1 ? w1.child[1] : w2.child[1]);
+        const int n2 = hit0 ? w0.child[2] : (hit1 ? w1.child[2] : w2.child[2]);
+        if ((hit0 | hit1 | hit2) && ++guard < 4096) {
+          node = next; ch0 = n0; ch1 = n1; ch2 = n2;
+          if (n0 == -1) state = FINISH;
+        } else {
+          todo[atomicAdd(todo_count, 1u)] = (int)k;
+          state = IDLE;
+        }
+      }
+    } else if (exhausted && !__ballot(state == FINISH)) {
+      break;
+    }
+  }
+#ifdef SINTERP_DIAG_PROF
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&g_walk_stats[0], it_step); atomicAdd(&g_walk_stats[1], lanes_step);
+    atomicAdd(&g_walk_stats[2], it_start); atomicAdd(&g_walk_stats[3], lanes_start);
+    atomicAdd(&g_walk_stats[4], it_finish); atomicAdd(&g_walk_stats[5], lanes_finish);
+  }
+#endif
+}
+
 template <bool FAST>
 __global__ void __launch_bounds__(256)
 bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, double s0, double s1,
                  const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
                  int *__restrict__ leaf_out, unsigned long long *__restrict__ n_outside, const int *__restrict__ perm,
-                 const int *__restrict__ jump, int G, const unsigned long long *__restrict__ box)
+                 const int *__restrict__ jump, int G, const unsigned long long *__restrict__ box,
+                 const unsigned *__restrict__ m_dev)
 {
+  if (m_dev) m = *m_dev;                       /* the queue bary_walk_kernel left (perm = its entries) */
   double jlo0 = 0, jlo1 = 0, jw0 = 0, jw1 = 0;
   if (jump) {
     jlo0 = key_to_double(box[0]); jlo1 = key_to_double(box[2]);
@@ -527,18 +826,51 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   size_t blocks = (m + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   static const bool no_fast = getenv("GSL_SINTERP_NO_FASTDIV") && getenv("GSL_SINTERP_NO_FASTDIV")[0] == '1';
+  static const bool no_affine = getenv("GSL_SINTERP_NO_AFFINE_WALK") && getenv("GSL_SINTERP_NO_AFFINE_WALK")[0] == '1';
+  const double *yt = sorted ? (const double *)srt.ys : d_targets;
+  const size_t yl = sorted ? (size_t)2 : ttda;
+  double *vt = sorted ? srt.vs : d_values;
+  int *lt = sorted ? (d_leaf ? srt.ls : (int *)NULL) : d_leaf;
+  const int *perm = NULL;
+  const unsigned *m_dev = NULL;
+  /* Large batches: per-batch affine walk records (a pass over the node records: ~n_nodes x 128 bytes) and the
+     certified walk; what it could not certify is queued for the exact kernel.  The results do not depend on
+     which kernel walked a target. */
+  if (!no_fast && !no_affine && sorted && m < 0x7fffffffULL && m >= (size_t)n_nodes / 8) {
+    void *wb = NULL;
+    int st = sinterp_walkbuf(ctx, (size_t)n_nodes * sizeof(WalkRec) + 64 + m * sizeof(int), &wb);
+    if (st) return st;
+    WalkRec *wrec = (WalkRec *)wb;
+    unsigned *todo_count = (unsigned *)((char *)wb + (size_t)n_nodes * sizeof(WalkRec));
+    int *todo = (int *)((char *)todo_count + 64);
+    HIP_OK(ctx, hipMemsetAsync(todo_count, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(walk_pack_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes,
+                       (const NodeRec *)d_records, h_scale[0], h_scale[1], wrec);
+    /* persistent waves, as many as are resident at once, drawing targets from a counter */
+    int cus = 0;
+    HIP_OK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    int per_cu = 0;                            /* resident workgroups per CU at the kernel's register budget */
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bary_walk_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    int batch = WALK_BATCH;
+    if (getenv("GSL_SINTERP_WALK_WGS_PER_CU")) per_cu = atoi(getenv("GSL_SINTERP_WALK_WGS_PER_CU")) > 0 ? atoi(getenv("GSL_SINTERP_WALK_WGS_PER_CU")) : per_cu;
+    if (getenv("GSL_SINTERP_WALK_BATCH")) batch = atoi(getenv("GSL_SINTERP_WALK_BATCH")) > 0 ? atoi(getenv("GSL_SINTERP_WALK_BATCH")) : batch;
+    size_t wblocks = (size_t)(cus > 0 ? cus : 256) * (size_t)per_cu;
+    if (wblocks > blocks) wblocks = blocks;
+    hipLaunchKernelGGL(bary_walk_kernel, dim3((unsigned)wblocks), dim3(256), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
+                       (const WalkRec *)wrec, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt,
+                       (const int *)d_jump, G, d_jbox, todo_count, todo, (unsigned long long *)(todo_count + 2), batch);
+    perm = todo;
+    m_dev = todo_count;
+    if (blocks > 2048) blocks = 2048;          /* the queue is normally (almost) empty */
+  }
   if (no_fast)
     hipLaunchKernelGGL(bary_eval_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
-                       (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1],
-                       sorted ? (const double *)srt.ys : d_targets, m, sorted ? (size_t)2 : ttda, sorted ? srt.vs : d_values,
-                       sorted ? (d_leaf ? srt.ls : (int *)NULL) : d_leaf, d_count, (const int *)NULL, (const int *)d_jump, G,
-                       d_jbox);
+                       (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt, d_count,
+                       perm, (const int *)d_jump, G, d_jbox, m_dev);
   else
     hipLaunchKernelGGL(bary_eval_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
-                       (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1],
-                       sorted ? (const double *)srt.ys : d_targets, m, sorted ? (size_t)2 : ttda, sorted ? srt.vs : d_values,
-                       sorted ? (d_leaf ? srt.ls : (int *)NULL) : d_leaf, d_count, (const int *)NULL, (const int *)d_jump, G,
-                       d_jbox);
+                       (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt, d_count,
+                       perm, (const int *)d_jump, G, d_jbox, m_dev);
   LAUNCH_CHECK(ctx);
   if (sorted) {
     int st = sinterp_unsort(ctx, &srt, m, d_values, d_leaf);

@@ -32,6 +32,8 @@ struct gsl_sinterp_hip_ctx {
   size_t sort2_bytes;
   void *d_cent;             /* cell-ordered packed centres {x, w} + tile boxes of the Gaussian sweep */
   size_t cent_bytes;
+  void *d_walk;             /* affine walk records + queue of the barycentric walk (bary.hip), rebuilt per batch */
+  size_t walk_bytes;
   /* hipGraph cache: the recursive factorisation drivers issue ~1-2k small, fully static
      launches; they are captured once per (routine, n, lda, pointers) and replayed */
   hipStream_t cap_stream;
@@ -175,6 +177,7 @@ int sinterp_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, 
 int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, size_t xtda, int dim, int per_cell,
                          int **d_perm_out);
 int sinterp_sortbuf2(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
+int sinterp_walkbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 /* sort.hip: bounding box of n points as order-preserving keys, box[2c] = min, box[2c+1] = max (device, 48 bytes) */
 int sinterp_bbox_keys(gsl_sinterp_hip_ctx *ctx, const double *d_p, size_t n, size_t tda, int dim, unsigned long long *d_box);
 int sinterp_centbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);

@@ -79,6 +79,7 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_sort) (void)hipFree(ctx->d_sort);
   if (ctx->d_sort2) (void)hipFree(ctx->d_sort2);
   if (ctx->d_cent) (void)hipFree(ctx->d_cent);
+  if (ctx->d_walk) (void)hipFree(ctx->d_walk);
   if (ctx->d_sk_partial) (void)hipFree(ctx->d_sk_partial);
   if (ctx->d_sk_flags) (void)hipFree(ctx->d_sk_flags);
   if (ctx->d_sk_tiles) (void)hipFree(ctx->d_sk_tiles);
@@ -330,6 +331,7 @@ static int grow_buf(gsl_sinterp_hip_ctx *ctx, void **buf, size_t *have, size_t b
   return ST_SUCCESS;
 }
 int sinterp_sortbuf2(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out) { return grow_buf(ctx, &ctx->d_sort2, &ctx->sort2_bytes, bytes, out); }
+int sinterp_walkbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out) { return grow_buf(ctx, &ctx->d_walk, &ctx->walk_bytes, bytes, out); }
 int sinterp_centbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out) { return grow_buf(ctx, &ctx->d_cent, &ctx->cent_bytes, bytes, out); }
 
 /* u(k) = (splitmix64(seed ^ k) >> 11) * 2^-53, out[i] = offset + span * u(first + i)
