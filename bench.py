@@ -348,15 +348,16 @@ def rooflines(cfg, name, n, dim, m_rank, ph, extra=None, gemm=None):
     if cfg["kind"] == "bary":
         t = ph["bary_eval"] * 1e-3
         by = 28.0 * m_rank                               # 16 B target in, 8 B value + 4 B leaf out
-        pmc = committed_pmc(name, "bary_eval_kernel")
-        res["roofline"] = {"kernel": "bary_eval_kernel (+ cell sort / gather / un-sort of the targets)", "bound": "hbm",
+        pmc = committed_pmc(name, "bary_walk_kernel")
+        res["roofline"] = {"kernel": "bary_walk_kernel (+ start / finish kernels, cell sort / gather / un-sort of the targets)", "bound": "hbm",
                            "achieved": round(by / t / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 6),
                            "traffic": pmc["hbm_traffic_bytes_per_launch"] if pmc and "hbm_traffic_bytes_per_launch" in pmc else None,
                            "traffic_source": pmc["source"] if pmc else None,
-                           "note": "the algorithmic HBM stream is 28 B/target; the sweep is bound by the dependent-gather "
-                                   "latency of the DAG walk (records resident in Infinity Cache) and by its two IEEE fp64 "
-                                   "divides per containment test, not by HBM"}
+                           "note": "the algorithmic HBM stream is 28 B/target; about half of the step is the cell sort of the "
+                                   "targets (one returning atomic per target) and the un-sort gather, the other half the DAG "
+                                   "walk, which is bound by the latency of its dependent 64-byte gathers (records resident in "
+                                   "L2 / Infinity Cache), not by HBM"}
         res["eval_only_mpts"] = round(m_rank / t / 1e6, 3)
         return res
     route = (extra or {}).get("route", {}).get("route", 1)

@@ -391,9 +391,8 @@ __device__ __forceinline__ void classify_affine(const WalkRec &w, double y0, dou
 }
 
 #ifdef SINTERP_DIAG_PROF
-/* developer build (make prof, tools/walk_stats.py): wave-iterations and active lanes of the three phases of
-   bary_walk_kernel: [0] step iterations, [1] lanes stepping, [2] start phases, [3] lanes started, [4] finish phases,
-   [5] lanes finished */
+/* developer build (make prof, tools/walk_stats.py): wave-iterations and active lanes of bary_walk_kernel:
+   [0] step iterations, [1] lanes stepping, [2] refills, [3] lanes refilled */
 __device__ unsigned long long g_walk_stats[40];
 extern "C" int gsl_sinterp_hip_debug_walk_stats(unsigned long long *out, int reset)
 {
@@ -403,24 +402,37 @@ extern "C" int gsl_sinterp_hip_debug_walk_stats(unsigned long long *out, int res
 }
 #endif
 
-/* The walk lengths of the targets of one wave differ widely (C5: 40 % of the targets start in their leaf, the mean
-   is 6.5 steps, yet the longest of 64 neighbours averages 24): a wave that keeps a target per lane until all 64 are
-   done runs at 27 % lane utilisation.  Here a lane is a worker: when enough lanes of a wave are idle the wave draws
-   that many new targets from a global counter (consecutive indices of the cell-sorted order, so the wave's lanes
-   still walk neighbouring parts of the DAG), and the three phases -- start (jump table + start node), step (test the
-   children), finish (exact coordinates in the leaf, store) -- each run for the lanes in that state under a
-   wave-uniform condition; start and finish are batched (>= WALK_BATCH lanes, or nothing else to do). */
+/* The certified walk is three kernels over the cell-sorted targets.
+   bary_start_kernel   one thread per target, streaming: jump table -> start node, certified containment in it; a
+                       target whose start node is its leaf (C5: 40 %) is finished here (exact coordinates, store); the
+                       others ("walkers") are packed, per workgroup of 256 targets, into that workgroup's 256-entry
+                       slice of the walker list {y, node, children} (ballot ranks, no global atomic);
+   bary_walk_kernel    persistent waves, a lane is a worker: the walk lengths of 64 neighbouring targets differ widely
+                       (mean 6.5 steps, but the longest of 64 averages 24), so a wave that kept one target per lane
+                       until all were done ran at 27 % lane utilisation.  When enough lanes are idle the wave draws
+                       that many walkers (slices are handed out through one counter, one atomic per slice; one atomic
+                       per refill serialised ~500k same-address atomics: 7 ms); their list entries are loaded in the
+                       same burst as the step's gathers, so a refill costs no extra memory round trip.  A lane that
+                       reaches its leaf records the node in the list and is idle again;
+   bary_finish_kernel  one thread per list entry, streaming: exact coordinates in the located leaf (interp_point
+                       recomputes them: the reference's arithmetic), values and leaves stored.
+   A target that meets an uncertified test anywhere goes to the queue of the exact kernel. */
 #define WALK_BATCH 16
-#define WALK_CHUNK 256
-/* Gathers.  A lane that reads its own 64-byte record with four 16-byte loads costs the CU's L1 four cache-line
-   look-ups per record, and the L1 serves about one line per clock: with 64 lanes on 64 different lines the step's
-   twelve loads took ~770 clocks per wave and bounded the kernel (measured: the time did not move with occupancy 3..7
-   nor with half the VALU work).  Instead the four lanes of a quad fetch ONE record per instruction, 16 bytes each
-   (one line per quad), straight into LDS (global_load_lds_dwordx4, lane l -> base + 16 l), four instructions per
-   child = the records of the quad's four lanes; a lane then reads its record back with four ds_read_b128.  The
-   per-instruction LDS images are 1040 bytes apart so that the 16 lanes of a read pass hit 64 different banks. */
+#define WALK_SLICE 256
+/* Gathers of the walk.  A lane that reads its own 64-byte record with four 16-byte loads costs the CU's L1 four
+   cache-line look-ups per record, and the L1 serves about one line per clock: with 64 lanes on 64 different lines
+   the step's twelve loads took ~770 clocks per wave and bounded the kernel (measured: the time did not move with
+   occupancy 3..7 nor with half the VALU work).  Instead the four lanes of a quad fetch ONE record per instruction,
+   16 bytes each (one line per quad), straight into LDS (global_load_lds_dwordx4, lane l -> base + 16 l), four
+   instructions per child = the records of the quad's four lanes; a lane then reads its record back with four
+   ds_read_b128.  The per-instruction LDS images are 1040 bytes apart so that the 16 lanes of a read pass hit 64
+   different banks. */
 #define WALK_IMG 1040
-#define WALK_WAVE_LDS (12 * WALK_IMG)
+#define WALK_WAVE_LDS (8 * WALK_IMG)
+/* Only the first two children are fetched per step (eight images per wave, one wave per workgroup: 19 waves per CU
+   instead of 12 with all three -- the walk is bound by the latency of its gathers, and 85 % of the DAG's inner nodes
+   are flips with two children).  A lane whose two tests both say "certainly not" at a three-child node takes the
+   third child in a step of its own. */
 
 template <int J>
 __device__ __forceinline__ int quad_bcast(int v)          /* lane J of the quad -> all four */
@@ -441,155 +453,208 @@ __device__ __forceinline__ WalkRec lds_rec(const char *p)
   u.q[0] = q[0]; u.q[1] = q[1]; u.q[2] = q[2]; u.q[3] = q[3];
   return u.r;
 }
-__global__ void __launch_bounds__(256)
-bary_walk_kernel(int n_nodes, const NodeRec *__restrict__ rec, const WalkRec *__restrict__ wrec,
-                 const LeafRec *__restrict__ tab, double s0, double s1, const double *__restrict__ targets, size_t m,
-                 size_t ttda, double *__restrict__ values, int *__restrict__ leaf_out, const int *__restrict__ jump, int G,
-                 const unsigned long long *__restrict__ box, unsigned *__restrict__ todo_count, int *__restrict__ todo,
-                 unsigned long long *__restrict__ next_target, int batch)
+
+/* packed: values is an array of {value, leaf} pairs (16 bytes, one store here and ONE gather per target in the
+   un-sort pass instead of two) */
+__device__ __forceinline__ void store_result(double *__restrict__ values, int *__restrict__ leaf_out, size_t k, double v, int leaf,
+                                             bool packed)
+{
+  if (packed) {
+    *reinterpret_cast<double2 *>(values + 2 * k) = make_double2(v, __longlong_as_double((long long)leaf));
+  } else {
+    values[k] = v;
+    if (leaf_out) leaf_out[k] = leaf;
+  }
+}
+
+/* exact coordinates in the located leaf, value and leaf stored (linear_simplex.c:678-711) */
+__device__ __forceinline__ void finish_target(const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, int node, double y0,
+                                              double y1, double s0, double s1, size_t k, double *__restrict__ values,
+                                              int *__restrict__ leaf_out, bool packed)
+{
+  const NodeRec cur = load_rec(rec, node);
+  double c0, c1;
+  solve_node(cur, y0, y1, s0, s1, c0, c1);
+  const LeafRec lr = tab[node];
+  double tot = 0, interp = 0;
+  tot += c0;
+  if (lr.mask & 1) interp += c0 * lr.f[0];
+  tot += c1;
+  if (lr.mask & 2) interp += c1 * lr.f[1];
+  if (lr.mask & 4) interp += (1 - tot) * lr.f[2];
+  store_result(values, leaf_out, k, interp, node, packed);
+}
+
+/* the walker list: slice b (entries [256 b, 256 b + count[b])) holds the walkers among targets [256 b, 256 b + 256) */
+struct WalkList {
+  double2 *y;        /* target */
+  int4 *st;          /* in: {node, child0, child1, child2}; out: .x = located leaf, -1 if queued for the exact kernel */
+  int *k;            /* position in the (sorted) target array */
+  unsigned *count;   /* per slice */
+};
+
+__global__ void __launch_bounds__(WALK_SLICE)
+bary_start_kernel(int n_nodes, const NodeRec *__restrict__ rec, const WalkRec *__restrict__ wrec, const LeafRec *__restrict__ tab,
+                  double s0, double s1, const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
+                  int *__restrict__ leaf_out, const int *__restrict__ jump, int G, const unsigned long long *__restrict__ box,
+                  unsigned *__restrict__ todo_count, int *__restrict__ todo, WalkList wl, int packed)
 {
   double jlo0 = 0, jlo1 = 0, jw0 = 0, jw1 = 0;
   if (jump) {
     jlo0 = key_to_double(box[0]); jlo1 = key_to_double(box[2]);
     jw0 = (key_to_double(box[1]) - jlo0) / G; jw1 = (key_to_double(box[3]) - jlo1) / G;
   }
-  __shared__ __attribute__((aligned(16))) char lds[4 * WALK_WAVE_LDS];
-  char *const img = lds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * WALK_WAVE_LDS;
-  const int lane = threadIdx.x & 63;
-  enum { IDLE = 0, WALK = 1, FINISH = 2 };
-  int state = IDLE, node = 0, ch0 = 0, ch1 = 0, ch2 = 0, guard = 0;
-  size_t k = 0;
+  __shared__ unsigned s_wave[4];
+  const size_t k = (size_t)blockIdx.x * WALK_SLICE + threadIdx.x;
+  bool walker = false;
+  double y0 = 0, y1 = 0;
+  int node = 0;
+  WalkRec cw;
+  cw.child[0] = cw.child[1] = cw.child[2] = 0;
+  if (k < m) {
+    y0 = targets[k * ttda]; y1 = targets[k * ttda + 1];
+    if (jump && jw0 > 0.0 && jw1 > 0.0 && y0 == y0 && y1 == y1) {       /* same start as bary_eval_kernel */
+      int ix = (int)((y0 - jlo0) / jw0), iy = (int)((y1 - jlo1) / jw1);
+      ix = ix < 0 ? 0 : (ix >= G ? G - 1 : ix);
+      iy = iy < 0 ? 0 : (iy >= G ? G - 1 : iy);
+      const bool in_cell = y0 >= jlo0 + jw0 * ix - JUMP_SLACK * jw0 && y0 <= jlo0 + jw0 * (ix + 1) + JUMP_SLACK * jw0 &&
+                           y1 >= jlo1 + jw1 * iy - JUMP_SLACK * jw1 && y1 <= jlo1 + jw1 * (iy + 1) + JUMP_SLACK * jw1;
+      const int start = in_cell ? jump[iy * G + ix] : 0;
+      if (start > 0 && start < n_nodes) node = start;
+    }
+    cw = load_wrec(wrec, node);
+    /* the start node (a jump-table node or the caging simplex) must certainly contain the target */
+    bool in, out;
+    classify_affine(cw, y0, y1, in, out);
+    if (!in) todo[atomicAdd(todo_count, 1u)] = (int)k;                  /* the exact walk takes it */
+    else if (cw.child[0] == -1) finish_target(rec, tab, node, y0, y1, s0, s1, k, values, leaf_out, packed != 0);
+    else walker = true;
+  }
+  const unsigned long long wmask = __ballot(walker);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_wave[wave] = (unsigned)__popcll(wmask);
+  __syncthreads();
+  unsigned base = 0, total = 0;
+  for (int w = 0; w < 4; w++) { if (w < wave) base += s_wave[w]; total += s_wave[w]; }
+  if (walker) {
+    const size_t p = (size_t)blockIdx.x * WALK_SLICE + base + (unsigned)__popcll(wmask & ((1ULL << lane) - 1ULL));
+    wl.y[p] = make_double2(y0, y1);
+    wl.st[p] = make_int4(node, cw.child[0], cw.child[1], cw.child[2]);
+    wl.k[p] = (int)k;
+  }
+  if (threadIdx.x == 0) wl.count[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(64)
+bary_walk_kernel(const WalkRec *__restrict__ wrec, WalkList wl, unsigned n_slices, unsigned *__restrict__ todo_count,
+                 int *__restrict__ todo, unsigned long long *__restrict__ next_slice, int batch)
+{
+  __shared__ __attribute__((aligned(16))) char img[WALK_WAVE_LDS];
+  const int lane = threadIdx.x;
+  bool walking = false;
+  int node = 0, ch0 = 0, ch1 = 0, ch2 = 0, guard = 0;
+  unsigned p = 0;                                          /* the lane's list entry */
   double y0 = 0, y1 = 0;
   bool exhausted = false;                                  /* wave-uniform */
-  unsigned long long cbeg = 0, cend = 0;                   /* wave-uniform: what is left of the wave's current chunk */
+  unsigned cbeg = 0, cend = 0;                             /* wave-uniform: what is left of the wave's current slice */
 #ifdef SINTERP_DIAG_PROF
-  unsigned long long it_step = 0, it_start = 0, it_finish = 0, lanes_step = 0, lanes_start = 0, lanes_finish = 0;
+  unsigned long long it_step = 0, it_start = 0, lanes_step = 0, lanes_start = 0;
 #endif
   for (;;) {
-    const unsigned long long walking = __ballot(state == WALK);
-    /* ---- finish: exact coordinates in the located leaf (interp_point recomputes them: the reference's arithmetic) */
-    const unsigned long long finishing = __ballot(state == FINISH);
-    if (finishing && (__popcll(finishing) >= batch || !walking)) {
-#ifdef SINTERP_DIAG_PROF
-      it_finish++; lanes_finish += __popcll(finishing);
-#endif
-      if (state == FINISH) {
-        const NodeRec cur = load_rec(rec, node);
-        double c0, c1;
-        solve_node(cur, y0, y1, s0, s1, c0, c1);
-        const LeafRec lr = tab[node];
-        double tot = 0, interp = 0;
-        tot += c0;
-        if (lr.mask & 1) interp += c0 * lr.f[0];
-        tot += c1;
-        if (lr.mask & 2) interp += c1 * lr.f[1];
-        if (lr.mask & 4) interp += (1 - tot) * lr.f[2];
-        values[k] = interp;
-        if (leaf_out) leaf_out[k] = node;
-        state = IDLE;
-      }
-    }
-    /* ---- start: new targets for the idle lanes */
-    const unsigned long long idle = __ballot(state == IDLE);
-    if (!exhausted && idle && (__popcll(idle) >= batch || !walking)) {
-      unsigned nidle = (unsigned)__popcll(idle);
+    const unsigned long long wmask = __ballot(walking);
+    if (!wmask && exhausted) break;
+    /* ---- refill: list entries for the idle lanes, loaded together with the step's gathers */
+    bool fresh = false;
+    int4 nst = make_int4(0, 0, 0, 0);
+    double2 ny = make_double2(0, 0);
+    const unsigned nidle_all = 64u - (unsigned)__popcll(wmask);
+    if (!exhausted && (nidle_all >= (unsigned)batch || !wmask)) {
       if (cbeg == cend) {
-        /* one atomic per WALK_CHUNK targets (one per refill serialises ~500k same-address atomics: 7 ms) */
         unsigned long long got = 0;
-        if ((threadIdx.x & 63) == 0) got = atomicAdd(next_target, (unsigned long long)WALK_CHUNK);
-        got = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) |
-              (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)got);
-        cbeg = got < m ? got : m;
-        cend = got + WALK_CHUNK < m ? got + WALK_CHUNK : m;
-      }
-      const unsigned long long base = cbeg;
-      if (nidle > cend - cbeg) nidle = (unsigned)(cend - cbeg);
-      cbeg += nidle;
-      exhausted = cbeg >= m;                               /* the chunk that ended at m was the last one */
-#ifdef SINTERP_DIAG_PROF
-      it_start++; lanes_start += nidle;
-#endif
-      if (state == IDLE) {
-        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-        k = base + rank;
-        if (rank < nidle) {
-          y0 = targets[k * ttda]; y1 = targets[k * ttda + 1];
-          node = 0;
-          if (jump && jw0 > 0.0 && jw1 > 0.0 && y0 == y0 && y1 == y1) {       /* same start as bary_eval_kernel */
-            int ix = (int)((y0 - jlo0) / jw0), iy = (int)((y1 - jlo1) / jw1);
-            ix = ix < 0 ? 0 : (ix >= G ? G - 1 : ix);
-            iy = iy < 0 ? 0 : (iy >= G ? G - 1 : iy);
-            const bool in_cell = y0 >= jlo0 + jw0 * ix - JUMP_SLACK * jw0 && y0 <= jlo0 + jw0 * (ix + 1) + JUMP_SLACK * jw0 &&
-                                 y1 >= jlo1 + jw1 * iy - JUMP_SLACK * jw1 && y1 <= jlo1 + jw1 * (iy + 1) + JUMP_SLACK * jw1;
-            const int start = in_cell ? jump[iy * G + ix] : 0;
-            if (start > 0 && start < n_nodes) node = start;
-          }
-          const WalkRec cw = load_wrec(wrec, node);
-          guard = 0;
-          /* the start node (a jump-table node or the caging simplex) must certainly contain the target */
-          bool in, out;
-          classify_affine(cw, y0, y1, in, out);
-          if (in) {
-            ch0 = cw.child[0]; ch1 = cw.child[1]; ch2 = cw.child[2];
-            state = ch0 == -1 ? FINISH : WALK;
-          } else {
-            todo[atomicAdd(todo_count, 1u)] = (int)k;                           /* the exact walk takes it */
-          }
+        if (lane == 0) got = atomicAdd(next_slice, 1ULL);
+        const unsigned slice = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)got);
+        if (slice < n_slices) {
+          cbeg = slice * WALK_SLICE;
+          cend = cbeg + (unsigned)__builtin_amdgcn_readfirstlane((int)wl.count[slice]);
+        } else {
+          exhausted = true;
         }
       }
+      unsigned take = cend - cbeg;
+      if (take > nidle_all) take = nidle_all;
+      const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(~wmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)~wmask, 0u));
+      if (!walking && rank < take) {
+        p = cbeg + rank;
+        nst = wl.st[p];
+        ny = wl.y[p];
+        fresh = true;
+      }
+      cbeg += take;
+#ifdef SINTERP_DIAG_PROF
+      it_start++; lanes_start += take;
+#endif
     }
+    /* ---- step gathers (all 64 lanes): instruction (child c, j) fetches the child-c record of the quad's lane j */
+    if (wmask) {
+      const int e0 = walking ? ch0 : 0, e1 = walking ? ch1 : 0;
+      const int part = lane & 3;
+#define WALK_FETCH(C, E, J) { const int idx = quad_bcast<J>(E); if (idx > 0) dma_part(wrec, idx, part, img + ((C) * 4 + (J)) * WALK_IMG); }
+      WALK_FETCH(0, e0, 0) WALK_FETCH(0, e0, 1) WALK_FETCH(0, e0, 2) WALK_FETCH(0, e0, 3)
+      WALK_FETCH(1, e1, 0) WALK_FETCH(1, e1, 1) WALK_FETCH(1, e1, 2) WALK_FETCH(1, e1, 3)
+#undef WALK_FETCH
+#ifdef SINTERP_DIAG_PROF
+      it_step++; lanes_step += __popcll(wmask);
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     /* ---- step: the reference's order -- the first child that certainly contains the target, all earlier ones
        certainly not; anything else (also: no child certainly contains it, the reference's least-violation
        fallback) goes to the exact walk */
-    if (__ballot(state == WALK)) {
-#ifdef SINTERP_DIAG_PROF
-      it_step++; lanes_step += __popcll(__ballot(state == WALK));
-#endif
-      {
-        /* all 64 lanes: instruction (child c, j) fetches the child-c record of the quad's lane j */
-        const int e0 = state == WALK ? ch0 : 0, e1 = state == WALK ? ch1 : 0, e2 = state == WALK ? ch2 : 0;
-        const int part = lane & 3;
-#define WALK_FETCH(C, E, J) { const int idx = quad_bcast<J>(E); if (idx > 0) dma_part(wrec, idx, part, img + ((C) * 4 + (J)) * WALK_IMG); }
-        WALK_FETCH(0, e0, 0) WALK_FETCH(0, e0, 1) WALK_FETCH(0, e0, 2) WALK_FETCH(0, e0, 3)
-        WALK_FETCH(1, e1, 0) WALK_FETCH(1, e1, 1) WALK_FETCH(1, e1, 2) WALK_FETCH(1, e1, 3)
-        WALK_FETCH(2, e2, 0) WALK_FETCH(2, e2, 1) WALK_FETCH(2, e2, 2) WALK_FETCH(2, e2, 3)
-#undef WALK_FETCH
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (walking) {
+      const char *mine = img + (lane & 3) * WALK_IMG + (lane & ~3) * 16;
+      const WalkRec w0 = lds_rec(mine), w1 = lds_rec(mine + 4 * WALK_IMG);
+      bool in0, out0, in1, out1;
+      classify_affine(w0, y0, y1, in0, out0);
+      classify_affine(w1, y0, y1, in1, out1);
+      const bool v0 = ch0 > 0, v1 = ch1 > 0;
+      const bool hit0 = v0 & in0, pass0 = !v0 | out0;                 /* pass: certainly not a hit */
+      const bool hit1 = pass0 & v1 & in1, pass1 = pass0 & (!v1 | out1);
+      if (hit0 | hit1) {
+        node = hit0 ? ch0 : ch1;
+        const int n0 = hit0 ? w0.child[0] : w1.child[0];
+        ch1 = hit0 ? w0.child[1] : w1.child[1];
+        ch2 = hit0 ? w0.child[2] : w1.child[2];
+        ch0 = n0;
+        if (++guard >= 4096) { todo[atomicAdd(todo_count, 1u)] = wl.k[p]; wl.st[p].x = -1; walking = false; }
+        else if (n0 == -1) { wl.st[p].x = node; walking = false; }     /* located: bary_finish_kernel takes over */
+      } else if (pass1 & (ch2 > 0)) {
+        ch0 = ch2; ch1 = 0; ch2 = 0;                                   /* both certainly not: the third child, alone */
+      } else {
+        todo[atomicAdd(todo_count, 1u)] = wl.k[p];
+        wl.st[p].x = -1;
+        walking = false;
       }
-      if (state == WALK) {
-        const char *mine = img + (lane & 3) * WALK_IMG + (lane & ~3) * 16;
-        const WalkRec w0 = lds_rec(mine), w1 = lds_rec(mine + 4 * WALK_IMG), w2 = lds_rec(mine + 8 * WALK_IMG);
-        bool in0, out0, in1, out1, in2, out2;
-        classify_affine(w0, y0, y1, in0, out0);
-        classify_affine(w1, y0, y1, in1, out1);
-        classify_affine(w2, y0, y1, in2, out2);
-        const bool v0 = ch0 > 0, v1 = ch1 > 0, v2 = ch2 > 0;
-        const bool hit0 = v0 & in0, pass0 = !v0 | out0;                 /* pass: certainly not a hit */
-        const bool hit1 = pass0 & v1 & in1, pass1 = pass0 & (!v1 | out1);
-        const bool hit2 = pass1 & v2 & in2;
-        const int next = hit0 ? ch0 : (hit1 ? ch1 : ch2);
-        const int n0 = hit0 ? w0.child[0] : (hit1 ? w1.child[0] : w2.child[0]);
-        const int n1 = hit0 ? w0.child[1] : (hit1 ? w1.child[1] : w2.child[1]);
-        const int n2 = hit0 ? w0.child[2] : (hit1 ? w1.child[2] : w2.child[2]);
-        if ((hit0 | hit1 | hit2) && ++guard < 4096) {
-          node = next; ch0 = n0; ch1 = n1; ch2 = n2;
-          if (n0 == -1) state = FINISH;
-        } else {
-          todo[atomicAdd(todo_count, 1u)] = (int)k;
-          state = IDLE;
-        }
-      }
-    } else if (exhausted && !__ballot(state == FINISH)) {
-      break;
     }
+    if (fresh) { node = nst.x; ch0 = nst.y; ch1 = nst.z; ch2 = nst.w; y0 = ny.x; y1 = ny.y; guard = 0; walking = true; }
   }
 #ifdef SINTERP_DIAG_PROF
-  if ((threadIdx.x & 63) == 0) {
+  if (lane == 0) {
     atomicAdd(&g_walk_stats[0], it_step); atomicAdd(&g_walk_stats[1], lanes_step);
     atomicAdd(&g_walk_stats[2], it_start); atomicAdd(&g_walk_stats[3], lanes_start);
-    atomicAdd(&g_walk_stats[4], it_finish); atomicAdd(&g_walk_stats[5], lanes_finish);
   }
 #endif
+}
+
+__global__ void __launch_bounds__(WALK_SLICE)
+bary_finish_kernel(const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, double s0, double s1, WalkList wl,
+                   double *__restrict__ values, int *__restrict__ leaf_out, int packed)
+{
+  if (threadIdx.x >= wl.count[blockIdx.x]) return;
+  const size_t p = (size_t)blockIdx.x * WALK_SLICE + threadIdx.x;
+  const int node = wl.st[p].x;
+  if (node < 0) return;                                     /* queued for the exact kernel */
+  const double2 y = wl.y[p];
+  finish_target(rec, tab, node, y.x, y.y, s0, s1, (size_t)wl.k[p], values, leaf_out, packed != 0);
 }
 
 template <bool FAST>
@@ -598,7 +663,7 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
                  const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
                  int *__restrict__ leaf_out, unsigned long long *__restrict__ n_outside, const int *__restrict__ perm,
                  const int *__restrict__ jump, int G, const unsigned long long *__restrict__ box,
-                 const unsigned *__restrict__ m_dev)
+                 const unsigned *__restrict__ m_dev, int packed)
 {
   if (m_dev) m = *m_dev;                       /* the queue bary_walk_kernel left (perm = its entries) */
   double jlo0 = 0, jlo1 = 0, jw0 = 0, jw1 = 0;
@@ -638,8 +703,7 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
       bool in_cage = false;
       if (!META_SINGULAR(cur.meta)) { solve_node(cur, y0, y1, s0, s1, c0, c1); in_cage = inside_unit(c0, c1); }
       if (!in_cage) {                                   /* linear_simplex.c:341-347 (q7: no abort) */
-        values[k] = __builtin_nan("");
-        if (leaf_out) leaf_out[k] = -1;
+        store_result(values, leaf_out, k, __builtin_nan(""), -1, packed != 0);
         atomicAdd(n_outside, 1ULL);
         continue;
       }
@@ -718,8 +782,7 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
     tot += c1;
     if (lr.mask & 2) interp += c1 * lr.f[1];
     if (lr.mask & 4) interp += (1 - tot) * lr.f[2];
-    values[k] = interp;
-    if (leaf_out) leaf_out[k] = node;
+    store_result(values, leaf_out, k, interp, node, packed != 0);
   }
 }
 
@@ -830,35 +893,56 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   const double *yt = sorted ? (const double *)srt.ys : d_targets;
   const size_t yl = sorted ? (size_t)2 : ttda;
   double *vt = sorted ? srt.vs : d_values;
-  int *lt = sorted ? (d_leaf ? srt.ls : (int *)NULL) : d_leaf;
+  int *lt = sorted ? (int *)NULL : d_leaf;
+  const int packed = sorted && d_leaf != NULL;             /* {value, leaf} pairs in srt.vs, see store_result */
   const int *perm = NULL;
   const unsigned *m_dev = NULL;
   /* Large batches: per-batch affine walk records (a pass over the node records: ~n_nodes x 128 bytes) and the
      certified walk; what it could not certify is queued for the exact kernel.  The results do not depend on
      which kernel walked a target. */
   if (!no_fast && !no_affine && sorted && m < 0x7fffffffULL && m >= (size_t)n_nodes / 8) {
+    const unsigned n_slices = (unsigned)((m + WALK_SLICE - 1) / WALK_SLICE);
+    const size_t mp = (size_t)n_slices * WALK_SLICE;
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t o_cnt = up((size_t)n_nodes * sizeof(WalkRec)), o_todo = o_cnt + 64, o_y = o_todo + up(m * sizeof(int)),
+                 o_st = o_y + up(mp * sizeof(double2)), o_k = o_st + up(mp * sizeof(int4)), o_sc = o_k + up(mp * sizeof(int)),
+                 bytes = o_sc + up((size_t)n_slices * sizeof(unsigned));
     void *wb = NULL;
-    int st = sinterp_walkbuf(ctx, (size_t)n_nodes * sizeof(WalkRec) + 64 + m * sizeof(int), &wb);
+    int st = sinterp_walkbuf(ctx, bytes, &wb);
     if (st) return st;
+    char *wbc = (char *)wb;
     WalkRec *wrec = (WalkRec *)wb;
-    unsigned *todo_count = (unsigned *)((char *)wb + (size_t)n_nodes * sizeof(WalkRec));
-    int *todo = (int *)((char *)todo_count + 64);
+    unsigned *todo_count = (unsigned *)(wbc + o_cnt);
+    int *todo = (int *)(wbc + o_todo);
+    WalkList wl;
+    wl.y = (double2 *)(wbc + o_y); wl.st = (int4 *)(wbc + o_st); wl.k = (int *)(wbc + o_k); wl.count = (unsigned *)(wbc + o_sc);
     HIP_OK(ctx, hipMemsetAsync(todo_count, 0, 64, ctx->stream));
     hipLaunchKernelGGL(walk_pack_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes,
                        (const NodeRec *)d_records, h_scale[0], h_scale[1], wrec);
-    /* persistent waves, as many as are resident at once, drawing targets from a counter */
-    int cus = 0;
-    HIP_OK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    int per_cu = 0;                            /* resident workgroups per CU at the kernel's register budget */
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bary_walk_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    hipLaunchKernelGGL(bary_start_kernel, dim3(n_slices), dim3(WALK_SLICE), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
+                       (const WalkRec *)wrec, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt,
+                       (const int *)d_jump, G, d_jbox, todo_count, todo, wl, packed);
+    /* persistent waves, as many as are resident at once, drawing slices of the walker list from a counter */
+    static int s_cus[64], s_per_cu[64];   /* per device, queried once */
+    const int dv = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    if (s_cus[dv] == 0) {
+      int c = 0, w = 0;                        /* w: resident workgroups per CU (the LDS images bound it) */
+      HIP_OK(ctx, hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, ctx->device));
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, bary_walk_kernel, 64, 0) != hipSuccess || w < 1) w = 16;
+      s_per_cu[dv] = w;
+      s_cus[dv] = c > 0 ? c : 256;
+    }
+    const int cus = s_cus[dv];
+    int per_cu = s_per_cu[dv];
     int batch = WALK_BATCH;
     if (getenv("GSL_SINTERP_WALK_WGS_PER_CU")) per_cu = atoi(getenv("GSL_SINTERP_WALK_WGS_PER_CU")) > 0 ? atoi(getenv("GSL_SINTERP_WALK_WGS_PER_CU")) : per_cu;
     if (getenv("GSL_SINTERP_WALK_BATCH")) batch = atoi(getenv("GSL_SINTERP_WALK_BATCH")) > 0 ? atoi(getenv("GSL_SINTERP_WALK_BATCH")) : batch;
     size_t wblocks = (size_t)(cus > 0 ? cus : 256) * (size_t)per_cu;
-    if (wblocks > blocks) wblocks = blocks;
-    hipLaunchKernelGGL(bary_walk_kernel, dim3((unsigned)wblocks), dim3(256), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
-                       (const WalkRec *)wrec, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt,
-                       (const int *)d_jump, G, d_jbox, todo_count, todo, (unsigned long long *)(todo_count + 2), batch);
+    if (wblocks > n_slices) wblocks = n_slices;
+    hipLaunchKernelGGL(bary_walk_kernel, dim3((unsigned)wblocks), dim3(64), 0, ctx->stream, (const WalkRec *)wrec, wl, n_slices,
+                       todo_count, todo, (unsigned long long *)(todo_count + 2), batch);
+    hipLaunchKernelGGL(bary_finish_kernel, dim3(n_slices), dim3(WALK_SLICE), 0, ctx->stream, (const NodeRec *)d_records,
+                       (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], wl, vt, lt, packed);
     perm = todo;
     m_dev = todo_count;
     if (blocks > 2048) blocks = 2048;          /* the queue is normally (almost) empty */
@@ -866,14 +950,14 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   if (no_fast)
     hipLaunchKernelGGL(bary_eval_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
                        (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt, d_count,
-                       perm, (const int *)d_jump, G, d_jbox, m_dev);
+                       perm, (const int *)d_jump, G, d_jbox, m_dev, packed);
   else
     hipLaunchKernelGGL(bary_eval_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_nodes,
                        (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt, d_count,
-                       perm, (const int *)d_jump, G, d_jbox, m_dev);
+                       perm, (const int *)d_jump, G, d_jbox, m_dev, packed);
   LAUNCH_CHECK(ctx);
   if (sorted) {
-    int st = sinterp_unsort(ctx, &srt, m, d_values, d_leaf);
+    int st = packed ? sinterp_unsort_packed(ctx, &srt, m, d_values, d_leaf) : sinterp_unsort(ctx, &srt, m, d_values, d_leaf);
     if (st) return st;
   }
   if (h_n_outside) {

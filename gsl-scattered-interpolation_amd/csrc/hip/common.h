@@ -163,7 +163,7 @@ int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
    the un-sort (a permutation-indirect kernel pays a scattered read AND partial-sector scattered writes). */
 struct sinterp_sorted {
   double *ys;                   /* [m][dim] targets in cell order */
-  double *vs;                   /* [m] values in cell order (filled by the sweep) */
+  double *vs;                   /* [m] values in cell order (filled by the sweep); room for [m] {value, leaf} pairs */
   int *ls;                      /* [m] leaf indices in cell order (barycentric sweep) */
   unsigned *cellid, *slot, *offset;
   unsigned long long *box;      /* bounding-box keys, box[2c] = min, box[2c+1] = max */
@@ -171,6 +171,8 @@ struct sinterp_sorted {
 int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
                          sinterp_sorted *out);
 int sinterp_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf);
+/* vs holds {value, leaf-as-integer-bits} pairs (16 bytes per target; the vs region is sized for it) */
+int sinterp_unsort_packed(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf);
 
 /* the centres: cells visited in Morton order (consecutive runs are spatially compact), original
    index order inside a cell (deterministic summation order); uses its own buffer */

@@ -354,7 +354,7 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   for (int c = 0; c < dim; c++) ncell *= (size_t)g;
   /* layout: box | ys | vs | ls | cellid | slot | count(+1) ; every section 16-byte aligned */
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  const size_t o_ys = 64, o_vs = o_ys + up(m * dim * 8), o_ls = o_vs + up(m * 8), o_cell = o_ls + up(m * 4),
+  const size_t o_ys = 64, o_vs = o_ys + up(m * dim * 8), o_ls = o_vs + up(m * 16), o_cell = o_ls + up(m * 4),
                o_slot = o_cell + up(m * 4), o_cnt = o_slot + up(m * 4), bytes = o_cnt + up((ncell + 1) * 4 + (ncell / 1024 + 8) * 4);
   void *buf = NULL;
   int st = sinterp_sortbuf(ctx, bytes, &buf);
@@ -373,6 +373,30 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   launch_cell_scan(ctx, out->offset, ncell, out->offset + ncell + 1);
   hipLaunchKernelGGL(cell_scatter_points_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim,
                      (const unsigned *)out->cellid, (const unsigned *)out->slot, (const unsigned *)out->offset, out->ys);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+__global__ void __launch_bounds__(256)
+unsort_packed_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ slot, const unsigned *__restrict__ offset, size_t m,
+                     const double2 *__restrict__ vl, double *__restrict__ values, int *__restrict__ leaf)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    const size_t pos = (size_t)offset[cellid[k]] + slot[k];
+    const double2 r = vl[pos];                                  /* one 16-byte gather */
+    values[k] = r.x;
+    leaf[k] = (int)__double_as_longlong(r.y);
+  }
+}
+
+int sinterp_unsort_packed(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf)
+{
+  if (m == 0) return ST_SUCCESS;
+  size_t blocks = (m + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unsort_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->cellid,
+                     (const unsigned *)s->slot, (const unsigned *)s->offset, m, (const double2 *)s->vs, d_values, d_leaf);
   LAUNCH_CHECK(ctx);
   return ST_SUCCESS;
 }

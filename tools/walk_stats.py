@@ -35,5 +35,5 @@ torch.cuda.synchronize()
 lib.gsl_sinterp_hip_debug_walk_stats(out, 1)
 s = [int(v) for v in out]
 print(f"nodes {nn}  targets {m}")
-for name, a, b in (("step", 0, 1), ("start", 2, 3), ("finish", 4, 5)):
+for name, a, b in (("step", 0, 1), ("refill", 2, 3)):
     print(f"{name:7s} wave-iterations {s[a]:10d}  lanes {s[b]:11d}  mean active lanes {s[b] / max(s[a], 1):5.1f} of 64")
