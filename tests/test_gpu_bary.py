@@ -277,3 +277,47 @@ def test_division_free_containment_margin(pkg, orc):
     assert st == 0
     assert np.array_equal(leaf, oleaf)
     assert np.array_equal(bits(vals), bits(ovals))
+
+
+@pytest.mark.parametrize("shape", ["uniform", "one_point", "horizontal_line", "two_clusters", "with_nan_and_outside"])
+def test_degenerate_large_batches_stay_bitexact(pkg, orc, shape):
+    """Large batches go through the cell sort, the start / walk / finish kernels and the un-sort gather.  Degenerate
+    batches stress the bookkeeping: every target in one cell (one counter takes every atomic), one populated grid
+    row, two far clusters (empty cells in between), NaN / outside targets (cell 0, exact kernel's queue).  Every
+    target must come back at its own position with the oracle's leaf and bits."""
+    n = 3000
+    rng = np.random.default_rng(31)
+    x = orc.synth_centres(n, 2)
+    f = orc.synth_response(x)
+    t, o = build_pair(pkg, orc, x)
+    d = t.device_alloc(0)
+    assert d.set_response(f) == 0
+    m = 300_000
+    lo, hi = x.min(axis=0), x.max(axis=0)
+    if shape == "uniform":
+        y = lo + (hi - lo) * rng.random((m, 2))
+    elif shape == "one_point":
+        y = np.tile(0.5 * (lo + hi), (m, 1))
+    elif shape == "horizontal_line":
+        y = np.column_stack([lo[0] + (hi[0] - lo[0]) * rng.random(m), np.full(m, 0.5 * (lo[1] + hi[1]))])
+    elif shape == "two_clusters":
+        y = np.concatenate([lo + 0.01 * (hi - lo) * rng.random((m // 2, 2)), hi - 0.01 * (hi - lo) * rng.random((m - m // 2, 2))])
+    else:
+        y = lo + (hi - lo) * rng.random((m, 2))
+        y[::1000] = np.nan
+        y[7::5000] = [1e9, -1e9]
+    y = np.ascontiguousarray(y)
+    st, vals, leaf = d.eval_many(y)
+    sub = np.unique(np.concatenate([np.arange(0, m, 37), np.arange(0, 2000), np.arange(m - 2000, m)]))
+    if shape == "with_nan_and_outside":                       # the oracle is asked about ordinary targets only
+        sub = sub[(sub % 1000 != 0) & (sub % 5000 != 7)]
+        assert np.all(np.isnan(vals[::1000]))
+    ovals, oleaf = o.eval_many(x, f, y[sub])
+    assert np.array_equal(leaf[sub], oleaf)
+    assert np.array_equal(bits(vals[sub]), bits(ovals))
+    if shape == "one_point":
+        assert np.all(leaf == leaf[0]) and np.all(bits(vals) == bits(vals[:1])[0])
+    if shape == "with_nan_and_outside":
+        assert st == pkg.capi.GSL_EDOM and np.all(leaf[7::5000] == -1) and np.all(np.isnan(vals[7::5000]))
+    else:
+        assert st == 0
