@@ -148,18 +148,20 @@ def run_config(env, name, steps, warmup):
         nn = tree.n_nodes
         rec = torch.empty(nn * 64, dtype=torch.uint8, device="cuda")
         tab = torch.empty(nn * 32, dtype=torch.uint8, device="cuda")
-        pack_ms = None
-        if rank == 0:
-            types, pidx, links = tree.arrays()
-            sh = tree.shuffle()
-            d_type, d_pidx, d_links = (torch.from_numpy(a).cuda() for a in (types, pidx, links))
-            d_pts, d_resp = torch.from_numpy(xh[sh]).cuda(), torch.from_numpy(fh[sh]).cuda()
-            ctx.timer_start()
-            ctx.tree_pack(nn, d_type.data_ptr(), d_pidx.data_ptr(), d_links.data_ptr(), n, d_pts.data_ptr(),
-                          tree.geom(), rec.data_ptr())
-            pack_ms = ctx.timer_stop()
-            ctx.tree_bind(nn, d_pidx.data_ptr(), n, d_resp.data_ptr(), tab.data_ptr())
-        pkg.sharding.broadcast_model([rec, tab], 0)      # model replication: one broadcast of the packed DAG
+        # model replication as in the library's device groups: rank 0's flat DAG arrays are broadcast
+        # (13 MB at C5), every rank packs its own records -- and with them the full-resolution jump table, which
+        # a rank that only received packed records would have to rebuild per batch at a coarser resolution
+        types, pidx, links = tree.arrays()
+        sh = tree.shuffle()
+        flat = [types, pidx, links, xh[sh], fh[sh]]
+        d_type, d_pidx, d_links, d_pts, d_resp = (torch.from_numpy(a).cuda() if rank == 0 else
+                                                  torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, device="cuda") for a in flat)
+        pkg.sharding.broadcast_model([d_type, d_pidx, d_links, d_pts, d_resp], 0)
+        ctx.timer_start()
+        ctx.tree_pack(nn, d_type.data_ptr(), d_pidx.data_ptr(), d_links.data_ptr(), n, d_pts.data_ptr(),
+                      tree.geom(), rec.data_ptr())
+        pack_ms = ctx.timer_stop()
+        ctx.tree_bind(nn, d_pidx.data_ptr(), n, d_resp.data_ptr(), tab.data_ptr())
         scale = tree.geom()[8:10]
         d_leaf = torch.empty(m_rank, dtype=torch.int32, device="cuda")
 
