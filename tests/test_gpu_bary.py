@@ -321,3 +321,37 @@ def test_degenerate_large_batches_stay_bitexact(pkg, orc, shape):
         assert st == pkg.capi.GSL_EDOM and np.all(leaf[7::5000] == -1) and np.all(np.isnan(vals[7::5000]))
     else:
         assert st == 0
+
+
+def test_large_batch_values_only_and_strided_targets(pkg, orc):
+    """The sorted path with no leaf output (un-sort of plain values, no {value, leaf} pairs) and with targets that
+    are the first two columns of a wider matrix (ttda = 5) must give the bits of the leaf-returning call."""
+    import torch
+    n = 4000
+    x = orc.synth_centres(n, 2)
+    f = orc.synth_response(x)
+    t, o = build_pair(pkg, orc, x)
+    nn = t.n_nodes
+    types, pidx, links = t.arrays()
+    sh = t.shuffle()
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_type, d_pidx, d_links = dev(types), dev(pidx), dev(links)
+    d_pts, d_resp = dev(x[sh]), dev(f[sh])
+    rec = torch.empty(nn * 64, dtype=torch.uint8, device="cuda")
+    tab = torch.empty(nn * 32, dtype=torch.uint8, device="cuda")
+    geom = t.geom()
+    ctx.tree_pack(nn, ptr(d_type), ptr(d_pidx), ptr(d_links), n, ptr(d_pts), geom, ptr(rec))
+    ctx.tree_bind(nn, ptr(d_pidx), n, ptr(d_resp), ptr(tab))
+    m = 50_000
+    wide = np.zeros((m, 5))
+    wide[:, :2] = orc.synth_targets(5, m, 2)
+    wide[:, 2:] = 1e30                                            # must never be read as coordinates
+    d_wide = dev(wide)
+    d_v = torch.empty(m, dtype=torch.float64, device="cuda")
+    d_l = torch.empty(m, dtype=torch.int32, device="cuda")
+    ctx.bary_eval(nn, ptr(rec), ptr(tab), geom[8:10], ptr(d_wide), m, 5, ptr(d_v), ptr(d_l))
+    ovals, oleaf = o.eval_many(x, f, np.ascontiguousarray(wide[:, :2]))
+    assert np.array_equal(d_l.cpu().numpy(), oleaf) and np.array_equal(bits(d_v.cpu().numpy()), bits(ovals))
+    d_v2 = torch.full((m,), -7.0, dtype=torch.float64, device="cuda")
+    ctx.bary_eval(nn, ptr(rec), ptr(tab), geom[8:10], ptr(d_wide), m, 5, ptr(d_v2), None)
+    assert np.array_equal(bits(d_v2.cpu().numpy()), bits(ovals))
