@@ -857,9 +857,57 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   HIP_OK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
   /* m >= 4096: the targets are gathered into grid-cell order, swept contiguously, and the results
      un-sorted afterwards (see sinterp_sort_reorder) */
+  static const bool no_fast = getenv("GSL_SINTERP_NO_FASTDIV") && getenv("GSL_SINTERP_NO_FASTDIV")[0] == '1';
+  static const bool no_affine = getenv("GSL_SINTERP_NO_AFFINE_WALK") && getenv("GSL_SINTERP_NO_AFFINE_WALK")[0] == '1';
+  static const bool no_side = getenv("GSL_SINTERP_NO_SIDE_STREAM") && getenv("GSL_SINTERP_NO_SIDE_STREAM")[0] == '1';
+  const bool will_sort = m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1');
+  /* Large batches: per-batch affine walk records (a pass over the node records: ~n_nodes x 128 bytes) and the
+     certified walk; what it could not certify is queued for the exact kernel.  The results do not depend on
+     which kernel walked a target. */
+  const bool use_walk = !no_fast && !no_affine && will_sort && m < 0x7fffffffULL && m >= (size_t)n_nodes / 8;
+  const unsigned n_slices = (unsigned)((m + WALK_SLICE - 1) / WALK_SLICE);
+  WalkRec *wrec = NULL;
+  unsigned *todo_count = NULL;
+  int *todo = NULL;
+  WalkList wl;
+  memset(&wl, 0, sizeof wl);
+  /* kernels of this evaluation that do not depend on each other run beside the main stream: the walk records are
+     built while the targets are sorted, the finish kernel runs beside the exact kernel's queue */
+  bool side = false;
+  if (use_walk) {
+    const size_t mp = (size_t)n_slices * WALK_SLICE;
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t o_cnt = up((size_t)n_nodes * sizeof(WalkRec)), o_todo = o_cnt + 64, o_y = o_todo + up(m * sizeof(int)),
+                 o_st = o_y + up(mp * sizeof(double2)), o_k = o_st + up(mp * sizeof(int4)), o_sc = o_k + up(mp * sizeof(int)),
+                 bytes = o_sc + up((size_t)n_slices * sizeof(unsigned));
+    void *wb = NULL;
+    int st = sinterp_walkbuf(ctx, bytes, &wb);
+    if (st) return st;
+    char *wbc = (char *)wb;
+    wrec = (WalkRec *)wb;
+    todo_count = (unsigned *)(wbc + o_cnt);
+    todo = (int *)(wbc + o_todo);
+    wl.y = (double2 *)(wbc + o_y); wl.st = (int4 *)(wbc + o_st); wl.k = (int *)(wbc + o_k); wl.count = (unsigned *)(wbc + o_sc);
+    if (!no_side && !ctx->side_stream) {
+      if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) ctx->side_stream = NULL;
+      for (int i = 0; i < 4 && ctx->side_stream; i++)
+        if (hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = NULL; }
+    }
+    side = !no_side && ctx->side_stream != NULL;
+    hipStream_t ps = ctx->stream;
+    if (side) {
+      HIP_OK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));          /* after whatever produced the records */
+      HIP_OK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+      ps = ctx->side_stream;
+    }
+    HIP_OK(ctx, hipMemsetAsync(todo_count, 0, 64, ps));
+    hipLaunchKernelGGL(walk_pack_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, ps, n_nodes,
+                       (const NodeRec *)d_records, h_scale[0], h_scale[1], wrec);
+    if (side) HIP_OK(ctx, hipEventRecord(ctx->side_ev[1], ctx->side_stream));
+  }
   sinterp_sorted srt;
   bool sorted = false;
-  if (m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1')) {
+  if (will_sort) {
     int st = sinterp_sort_reorder(ctx, d_targets, m, ttda, 2, 64, &srt);
     if (st) return st;
     sorted = true;
@@ -888,8 +936,6 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   }
   size_t blocks = (m + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  static const bool no_fast = getenv("GSL_SINTERP_NO_FASTDIV") && getenv("GSL_SINTERP_NO_FASTDIV")[0] == '1';
-  static const bool no_affine = getenv("GSL_SINTERP_NO_AFFINE_WALK") && getenv("GSL_SINTERP_NO_AFFINE_WALK")[0] == '1';
   const double *yt = sorted ? (const double *)srt.ys : d_targets;
   const size_t yl = sorted ? (size_t)2 : ttda;
   double *vt = sorted ? srt.vs : d_values;
@@ -897,28 +943,8 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   const int packed = sorted && d_leaf != NULL;             /* {value, leaf} pairs in srt.vs, see store_result */
   const int *perm = NULL;
   const unsigned *m_dev = NULL;
-  /* Large batches: per-batch affine walk records (a pass over the node records: ~n_nodes x 128 bytes) and the
-     certified walk; what it could not certify is queued for the exact kernel.  The results do not depend on
-     which kernel walked a target. */
-  if (!no_fast && !no_affine && sorted && m < 0x7fffffffULL && m >= (size_t)n_nodes / 8) {
-    const unsigned n_slices = (unsigned)((m + WALK_SLICE - 1) / WALK_SLICE);
-    const size_t mp = (size_t)n_slices * WALK_SLICE;
-    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
-    const size_t o_cnt = up((size_t)n_nodes * sizeof(WalkRec)), o_todo = o_cnt + 64, o_y = o_todo + up(m * sizeof(int)),
-                 o_st = o_y + up(mp * sizeof(double2)), o_k = o_st + up(mp * sizeof(int4)), o_sc = o_k + up(mp * sizeof(int)),
-                 bytes = o_sc + up((size_t)n_slices * sizeof(unsigned));
-    void *wb = NULL;
-    int st = sinterp_walkbuf(ctx, bytes, &wb);
-    if (st) return st;
-    char *wbc = (char *)wb;
-    WalkRec *wrec = (WalkRec *)wb;
-    unsigned *todo_count = (unsigned *)(wbc + o_cnt);
-    int *todo = (int *)(wbc + o_todo);
-    WalkList wl;
-    wl.y = (double2 *)(wbc + o_y); wl.st = (int4 *)(wbc + o_st); wl.k = (int *)(wbc + o_k); wl.count = (unsigned *)(wbc + o_sc);
-    HIP_OK(ctx, hipMemsetAsync(todo_count, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(walk_pack_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes,
-                       (const NodeRec *)d_records, h_scale[0], h_scale[1], wrec);
+  if (use_walk) {
+    if (side) HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));     /* walk records ready */
     hipLaunchKernelGGL(bary_start_kernel, dim3(n_slices), dim3(WALK_SLICE), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
                        (const WalkRec *)wrec, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt,
                        (const int *)d_jump, G, d_jbox, todo_count, todo, wl, packed);
@@ -941,8 +967,15 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
     if (wblocks > n_slices) wblocks = n_slices;
     hipLaunchKernelGGL(bary_walk_kernel, dim3((unsigned)wblocks), dim3(64), 0, ctx->stream, (const WalkRec *)wrec, wl, n_slices,
                        todo_count, todo, (unsigned long long *)(todo_count + 2), batch);
-    hipLaunchKernelGGL(bary_finish_kernel, dim3(n_slices), dim3(WALK_SLICE), 0, ctx->stream, (const NodeRec *)d_records,
+    hipStream_t fs = ctx->stream;
+    if (side) {                                  /* the finish kernel beside the exact kernel (disjoint targets) */
+      HIP_OK(ctx, hipEventRecord(ctx->side_ev[2], ctx->stream));
+      HIP_OK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[2], 0));
+      fs = ctx->side_stream;
+    }
+    hipLaunchKernelGGL(bary_finish_kernel, dim3(n_slices), dim3(WALK_SLICE), 0, fs, (const NodeRec *)d_records,
                        (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], wl, vt, lt, packed);
+    if (side) HIP_OK(ctx, hipEventRecord(ctx->side_ev[3], ctx->side_stream));
     perm = todo;
     m_dev = todo_count;
     if (blocks > 2048) blocks = 2048;          /* the queue is normally (almost) empty */
@@ -956,6 +989,7 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
                        (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt, d_count,
                        perm, (const int *)d_jump, G, d_jbox, m_dev, packed);
   LAUNCH_CHECK(ctx);
+  if (use_walk && side) HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[3], 0));   /* join the finish kernel */
   if (sorted) {
     int st = packed ? sinterp_unsort_packed(ctx, &srt, m, d_values, d_leaf) : sinterp_unsort(ctx, &srt, m, d_values, d_leaf);
     if (st) return st;

@@ -34,6 +34,8 @@ struct gsl_sinterp_hip_ctx {
   size_t cent_bytes;
   void *d_walk;             /* affine walk records + queue of the barycentric walk (bary.hip), rebuilt per batch */
   size_t walk_bytes;
+  hipStream_t side_stream;  /* bary.hip: independent kernels of one evaluation run beside the main stream */
+  hipEvent_t side_ev[4];    /* fork / join events of the side stream (created with the stream) */
   /* hipGraph cache: the recursive factorisation drivers issue ~1-2k small, fully static
      launches; they are captured once per (routine, n, lda, pointers) and replayed */
   hipStream_t cap_stream;

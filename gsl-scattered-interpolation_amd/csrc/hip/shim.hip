@@ -80,6 +80,8 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_sort2) (void)hipFree(ctx->d_sort2);
   if (ctx->d_cent) (void)hipFree(ctx->d_cent);
   if (ctx->d_walk) (void)hipFree(ctx->d_walk);
+  for (int i = 0; i < 4; i++) if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->d_sk_partial) (void)hipFree(ctx->d_sk_partial);
   if (ctx->d_sk_flags) (void)hipFree(ctx->d_sk_flags);
   if (ctx->d_sk_tiles) (void)hipFree(ctx->d_sk_tiles);
