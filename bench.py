@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the scattered-interpolation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2|C4|C5|C1] [--only]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2|C4|C5|C1|C4W] [--only]
 
 One "step" = one full pass of the hot path over one batch of synthetic input that is
 already resident in HBM (SURVEY.md 8(d) clouds, generated on the device):
@@ -48,6 +48,9 @@ CONFIGS = {
                label="C3: 3-D N=16384 Gaussian RBF (16k x 16k fp64 Cholesky), M=1M targets per GPU"),
     "C4": dict(kind="gaussian", dim=2, n=8192, m=10_000_000, shard="total",
                label="C4: 2-D N=8192 Gaussian RBF, M=10M targets sharded over the GPUs"),
+    # beyond BASELINE.json's configs (never part of the default line): the compactly supported kernel, C4's shape
+    "C4W": dict(kind="wendland", dim=2, n=8192, m=10_000_000, shard="total",
+                label="C4W: 2-D N=8192 Wendland-C2 RBF (support of 8 mean spacings), M=10M targets sharded over the GPUs"),
     "C5": dict(kind="bary", dim=2, n=50_000, m=10_000_000, shard="total",
                label="C5: 2-D N=50000 barycentric over host-built Delaunay DAG, M=10M targets sharded"),
 }
@@ -172,8 +175,8 @@ def run_config(env, name, steps, warmup):
                  "tree_pack_ms_once_per_tree": None if pack_ms is None else round(pack_ms, 3),
                  "tree_pack_note": "node records + per-cell jump table (jump_build_kernel), once per tree, outside the step"}
     else:
-        kind = pkg.RBF_GAUSSIAN if cfg["kind"] == "gaussian" else pkg.RBF_TPS
-        eps = 2.0 * n ** (1.0 / dim)
+        kind = {"gaussian": pkg.RBF_GAUSSIAN, "tps": pkg.RBF_TPS, "wendland": pkg.RBF_WENDLAND}[cfg["kind"]]
+        eps = (0.125 if cfg["kind"] == "wendland" else 2.0) * n ** (1.0 / dim)
         d_phi = torch.empty((n, n), dtype=f64, device="cuda") if rank == 0 else None
         d_w = torch.empty(n, dtype=f64, device="cuda")
         route_seen = {}
@@ -376,7 +379,7 @@ def rooflines(cfg, name, n, dim, m_rank, ph, extra=None, gemm=None):
                   "traffic": pmc.get("hbm_traffic_bytes_per_launch") if pmc else None,
                   "committed_pmc": pmc}
     pair_ops = n * m_rank
-    gauss = cfg["kind"] == "gaussian"
+    gauss = cfg["kind"] in ("gaussian", "wendland")        # the culled sweep
     ek = "rbf_eval_gauss_cull_kernel" if gauss else "rbf_eval_kernel"
     hbm = {"achieved": round(by / te / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / te / 1e9 / HBM_PEAK_GBS, 6),
            "note": "algorithmic bytes 8d+8 per target; ~1e-3 of the HBM roofline by construction (N pair evaluations per target)"}
@@ -442,8 +445,8 @@ def cpu_baseline(cfg, n, dim, m_total):
                 "sample": f"first {ms} of the {m_total} targets, N={n}; host DAG build {build:.2f} s (one-off, excluded on both sides)",
                 "all_cores": {"cores": ncores, "note": "not measured: the oracle tree keeps its scratch inside the tree like the "
                                                        "reference (linear_simplex.h:51-58), so one tree cannot be walked by several threads"}}
-    kind = 0 if cfg["kind"] == "gaussian" else 1
-    eps = orc.gaussian_eps(n, dim)
+    kind = {"gaussian": 0, "tps": 1, "wendland": 2}[cfg["kind"]]
+    eps = 0.125 * n ** (1.0 / dim) if kind == 2 else orc.gaussian_eps(n, dim)
     x = orc.synth_centres(n, dim)
     f = orc.synth_response(x)
     # --- factorisation + solves at N in {2048, 4096}, reference order, one thread; N^3 extrapolation
@@ -453,17 +456,17 @@ def cpu_baseline(cfg, n, dim, m_total):
             continue
         xs, fs = np.ascontiguousarray(x[:ns]), np.ascontiguousarray(f[:ns])
         t0 = time.perf_counter()
-        phi = orc.rbf_fill(kind, orc.gaussian_eps(ns, dim), xs)
+        phi = orc.rbf_fill(kind, 0.125 * ns ** (1.0 / dim) if kind == 2 else orc.gaussian_eps(ns, dim), xs)
         tfill = time.perf_counter() - t0
         t0 = time.perf_counter()
-        if kind == 0:
+        if kind != 1:
             st, llt = orc.cholesky_decomp1(phi)
             w = orc.cholesky_solve(llt, fs)
         else:
             lu, perm, _ = orc.lu_decomp(phi)
             st, w = orc.lu_solve(lu, perm, fs)
         dts = time.perf_counter() - t0
-        fl = (ns ** 3 / 3.0) if kind == 0 else (2.0 * ns ** 3 / 3.0)
+        fl = (ns ** 3 / 3.0) if kind != 1 else (2.0 * ns ** 3 / 3.0)
         fact[ns] = {"fill_s": round(tfill, 3), "factor_solve_s": round(dts, 3), "gflops": round(fl / dts / 1e9, 3)}
     ns_max = max(fact)
     fill_full = fact[ns_max]["fill_s"] * (n / ns_max) ** 2

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 GSL_SUCCESS, GSL_FAILURE = 0, -1
 GSL_EDOM, GSL_EFAULT, GSL_EINVAL, GSL_EFAILED, GSL_ENOMEM = 1, 3, 4, 5, 8
 GSL_EBADLEN, GSL_ENOTSQR, GSL_EUNIMPL = 19, 20, 24
-RBF_GAUSSIAN, RBF_TPS = 0, 1
+RBF_GAUSSIAN, RBF_TPS, RBF_WENDLAND = 0, 1, 2
 SOLVER_DEFAULT, SOLVER_CHOLESKY2, SOLVER_PCHOLESKY, SOLVER_LU_REFINE = 0, 1, 2, 3
 TREE_DEFAULT, TREE_NOSTANDARDIZE, TREE_ISOSCALE = 0, 1, 2
 TREE_RECORD_BYTES, TREE_LEAFTAB_BYTES = 64, 32
@@ -218,7 +218,7 @@ SIGNATURES = {
     "gsl_rng_get": (C.c_ulong, [_vp]),
     "gsl_rng_uniform_int": (C.c_ulong, [_vp, C.c_ulong]),
 }
-DATA_SYMBOLS = ["gsl_sinterp_rbf_gaussian", "gsl_sinterp_rbf_tps", "gsl_sinterp_linear_simplex",
+DATA_SYMBOLS = ["gsl_sinterp_rbf_gaussian", "gsl_sinterp_rbf_tps", "gsl_sinterp_rbf_wendland", "gsl_sinterp_linear_simplex",
                 "gsl_rng_mt19937", "gsl_rng_default"]
 
 
@@ -617,7 +617,7 @@ class DeviceTree:
 
 # ------------------------------------------------------------------ facade
 class Sinterp:
-    TYPES = {"gaussian": "gsl_sinterp_rbf_gaussian", "tps": "gsl_sinterp_rbf_tps",
+    TYPES = {"gaussian": "gsl_sinterp_rbf_gaussian", "tps": "gsl_sinterp_rbf_tps", "wendland": "gsl_sinterp_rbf_wendland",
              "linear_simplex": "gsl_sinterp_linear_simplex"}
 
     def __init__(self, kind, dim, size, device=0):

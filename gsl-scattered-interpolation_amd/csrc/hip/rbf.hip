@@ -97,6 +97,10 @@ __device__ __forceinline__ double phi_r2(double r2, double coef, const double *_
 {
   if (KIND == GSL_SINTERP_RBF_GAUSSIAN) {
     return exp2_tbl(r2 * coef, t0);                /* coef = -eps^2 log2(e) */
+  } else if (KIND == GSL_SINTERP_RBF_WENDLAND) {
+    /* coef = eps; exactly 0 at and beyond the support radius (u <= 0); a NaN distance stays NaN */
+    const double t = coef * sqrt(r2), u = 1.0 - t, u2 = u * u;
+    return u <= 0.0 ? 0.0 : (u2 * u2) * fma(4.0, t, 1.0);
   } else {
     /* r^2 ln r = 0.5 r^2 ln r^2; the 0.5 is folded into the caller's weight (coef = 0.5 in fill).
        r2 = 0 (target on a centre): log_tbl returns a finite value, the product is exactly 0 */
@@ -231,16 +235,23 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
         for (int t = 0; t < TPT; t++) { take[t] = r2[t] * coef > -72.0; need |= take[t]; }
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
       }
+      if (KIND == GSL_SINTERP_RBF_WENDLAND) {
+        /* outside the support the term is exactly 0: skipping it changes nothing (wave-uniform skip of the sqrt) */
+        bool need = false;
+#pragma unroll
+        for (int t = 0; t < TPT; t++) { take[t] = r2[t] * (coef * coef) < 1.0; need |= take[t]; }
+        if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+      }
 #pragma unroll
       for (int t = 0; t < TPT; t++) {
         const double a = fma(wj, phi_r2<KIND, LOG_COPIES>(r2[t], KIND == GSL_SINTERP_RBF_TPS ? 1.0 : coef, s_t0, lt_lane), acc[t]);
-        acc[t] = (KIND == GSL_SINTERP_RBF_GAUSSIAN && !take[t]) ? acc[t] : a;
+        acc[t] = (KIND != GSL_SINTERP_RBF_TPS && !take[t]) ? acc[t] : a;
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < TPT; t++)
-    if (kidx[t] < m) s[kidx[t]] = (KIND == GSL_SINTERP_RBF_GAUSSIAN && nan_target<DIM>(yy[t])) ? NAN : acc[t];
+    if (kidx[t] < m) s[kidx[t]] = (KIND != GSL_SINTERP_RBF_TPS && nan_target<DIM>(yy[t])) ? NAN : acc[t];
 }
 
 /* ------------------------------------------------------------------------ */
@@ -287,7 +298,9 @@ centre_pack_kernel(const double *__restrict__ x, size_t n, size_t xtda, const do
   }
 }
 
-template <int DIM, int TPT>
+/* KIND = Gaussian: cut-off 2^-72 of the kernel maximum (coef = -eps^2 log2 e); KIND = Wendland: the support
+   radius itself (coef = eps), so culling drops terms that are exactly 0 */
+template <int KIND, int DIM, int TPT>
 __global__ void __launch_bounds__(EV_THREADS)
 rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n, const double *__restrict__ tbox, unsigned ntiles,
                            const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm)
@@ -339,7 +352,7 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
         const double g = fmax(0.0, fmax(tl - bhi[c], blo[c] - th));
         d2 = fma(g, g, d2);
       }
-      keep = d2 * coef > -72.0;
+      keep = KIND == GSL_SINTERP_RBF_GAUSSIAN ? d2 * coef > -72.0 : d2 * (coef * coef) < 1.0;
     }
     const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
     if (lane == 0 && (base / 64 + wave) < nmask) s_mask[base / 64 + wave] = b;
@@ -369,7 +382,7 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
           r2[tt] = 0.0;
 #pragma unroll
           for (int c = 0; c < DIM; c++) { const double d = yy[tt][c] - xc[c]; r2[tt] = fma(d, d, r2[tt]); }
-          take[tt] = r2[tt] * coef > -72.0;
+          take[tt] = KIND == GSL_SINTERP_RBF_GAUSSIAN ? r2[tt] * coef > -72.0 : r2[tt] * (coef * coef) < 1.0;
           need |= take[tt];
         }
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
@@ -378,7 +391,7 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
            Morton order -- independent of the workgroup / wave the target landed in */
 #pragma unroll
         for (int tt = 0; tt < TPT; tt++) {
-          const double a = fma(wj, exp2_tbl(r2[tt] * coef, s_t0), acc[tt]);
+          const double a = fma(wj, phi_r2<KIND, 1>(r2[tt], coef, s_t0, (const double *)NULL), acc[tt]);
           acc[tt] = take[tt] ? a : acc[tt];
         }
       }
@@ -389,7 +402,7 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
     if (kidx[t] < m) s[kidx[t]] = nan_target<DIM>(yy[t]) ? NAN : acc[t];
 }
 
-template <int TPT>
+template <int KIND, int TPT>
 static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x, size_t n, int dim, size_t xtda, const double *d_w,
                             const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm)
 {
@@ -406,15 +419,15 @@ static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double 
   switch (dim) {
     case 1:
       hipLaunchKernelGGL((centre_pack_kernel<1>), dim3(ntiles), dim3(CT), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<1, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 1, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
     case 2:
       hipLaunchKernelGGL((centre_pack_kernel<2>), dim3(ntiles), dim3(CT), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<2, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 2, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
     default:
       hipLaunchKernelGGL((centre_pack_kernel<3>), dim3(ntiles), dim3(CT), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<3, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 3, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
   }
   LAUNCH_CHECK(ctx);
@@ -424,7 +437,13 @@ static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double 
 /* ------------------------------------------------------------------------ */
 static double kernel_coef(int kind, double eps)
 {
+  if (kind == GSL_SINTERP_RBF_WENDLAND) return eps;
   return kind == GSL_SINTERP_RBF_GAUSSIAN ? -(eps * eps) * 1.44269504088896340735992 : 0.5;
+}
+
+static bool known_kind(int kind)
+{
+  return kind == GSL_SINTERP_RBF_GAUSSIAN || kind == GSL_SINTERP_RBF_TPS || kind == GSL_SINTERP_RBF_WENDLAND;
 }
 
 template <int KIND>
@@ -453,13 +472,14 @@ int sinterp_rbf_fill_ex(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const do
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && lda >= n, ST_EINVAL);
-  REQUIRE(ctx, kind == GSL_SINTERP_RBF_GAUSSIAN || kind == GSL_SINTERP_RBF_TPS, ST_EINVAL);
+  REQUIRE(ctx, known_kind(kind), ST_EINVAL);
   REQUIRE(ctx, n == 0 || (d_x && d_phi), ST_EFAULT);
   REQUIRE(ctx, (n + 15) / 16 <= 65535, ST_EINVAL);
   if (n == 0) return ST_SUCCESS;
   int st = ensure_tables(ctx);
   if (st) return st;
   const double coef = kernel_coef(kind, eps);
+  if (kind == GSL_SINTERP_RBF_WENDLAND) return launch_fill<GSL_SINTERP_RBF_WENDLAND>(ctx, coef, d_x, n, dim, xtda, d_phi, lda, lower_only);
   return kind == GSL_SINTERP_RBF_GAUSSIAN ? launch_fill<GSL_SINTERP_RBF_GAUSSIAN>(ctx, coef, d_x, n, dim, xtda, d_phi, lda, lower_only)
                                           : launch_fill<GSL_SINTERP_RBF_TPS>(ctx, coef, d_x, n, dim, xtda, d_phi, lda, lower_only);
 }
@@ -486,16 +506,17 @@ extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, doub
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && ytda >= (size_t)dim, ST_EINVAL);
-  REQUIRE(ctx, kind == GSL_SINTERP_RBF_GAUSSIAN || kind == GSL_SINTERP_RBF_TPS, ST_EINVAL);
+  REQUIRE(ctx, known_kind(kind), ST_EINVAL);
   REQUIRE(ctx, m == 0 || (d_y && d_s && (n == 0 || (d_x && d_w))), ST_EFAULT);
   if (m == 0) return ST_SUCCESS;
   int st = ensure_tables(ctx);
   if (st) return st;
   const double coef = kernel_coef(kind, eps);
-  /* Gaussian: group the targets spatially so that whole waves skip negligible terms together
-     (TPS has no decay: nothing to skip, no sort) */
+  /* Gaussian / Wendland: group the targets spatially so that whole waves skip negligible (Wendland: zero) terms
+     together (TPS has no decay: nothing to skip, no sort) */
+  const bool local = kind != GSL_SINTERP_RBF_TPS;
   int *d_perm = NULL;
-  if (kind == GSL_SINTERP_RBF_GAUSSIAN && m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1')) {
+  if (local && m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1')) {
     st = sinterp_sort_targets(ctx, d_y, m, ytda, dim, 64, &d_perm);
     if (st) return st;
   }
@@ -506,9 +527,16 @@ extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, doub
      runs must not depend on the batch (a target's value is a function of the model and the target alone, so a
      batch split into shards -- or a single-point call -- returns the bits of the one-batch result): it is chosen
      by N only; small batches simply run the culled kernel without the target sort. */
-  if (kind == GSL_SINTERP_RBF_GAUSSIAN && !no_cull && n >= 1024 && (n + CT - 1) / CT <= CULL_MAX_TILES)
-    return small ? launch_eval_cull<1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
-                 : launch_eval_cull<2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
+  if (local && !no_cull && n >= 1024 && (n + CT - 1) / CT <= CULL_MAX_TILES) {
+    if (kind == GSL_SINTERP_RBF_WENDLAND)
+      return small ? launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
+                   : launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
+    return small ? launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
+                 : launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
+  }
+  if (kind == GSL_SINTERP_RBF_WENDLAND)
+    return small ? launch_eval<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
+                 : launch_eval<GSL_SINTERP_RBF_WENDLAND, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
   if (kind == GSL_SINTERP_RBF_GAUSSIAN)
     return small ? launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
                  : launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);

@@ -161,11 +161,12 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
   if (n == 0) return ST_SUCCESS;
   /* thin-plate spline: the shift and the row norms need the full matrix; Gaussian: the Cholesky reads the lower
      triangle only, the upper one (the "original kept above the diagonal" of cholesky.c:103) only when asked for */
-  int st = sinterp_rbf_fill_ex(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, kind == GSL_SINTERP_RBF_GAUSSIAN && !keep_upper);
+  const bool spd = kind != GSL_SINTERP_RBF_TPS;        /* Gaussian, Wendland: positive definite kernels */
+  int st = sinterp_rbf_fill_ex(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, spd && !keep_upper);
   if (st) return st;
   int info = 0;
 
-  if (kind == GSL_SINTERP_RBF_GAUSSIAN) {
+  if (spd) {
     st = sinterp_cholesky_decomp1_sym(ctx, n, d_phi, lda, &info);   /* the fill (and the shift) write both triangles */
     if (st) return st;
     if (h_route) *h_route = 1;
@@ -253,7 +254,7 @@ extern "C" int gsl_sinterp_hip_rbf_solve_ex(gsl_sinterp_hip_ctx *ctx, int kind, 
   if (h_rcond) *h_rcond = NAN;
   if (h_route) *h_route = 0;
   if (solver == GSL_SINTERP_SOLVER_DEFAULT) {
-    if (!h_rcond || kind != GSL_SINTERP_RBF_GAUSSIAN)
+    if (!h_rcond || kind == GSL_SINTERP_RBF_TPS)
       return gsl_sinterp_hip_rbf_solve(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, h_route);
     int route = 0;
     int st = rbf_solve_impl(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, &route, true);

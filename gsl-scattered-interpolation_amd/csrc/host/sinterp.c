@@ -524,6 +524,7 @@ static void *rbf_alloc_kind(int kind, size_t dim, size_t size)
 }
 static void *rbf_gauss_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_GAUSSIAN, dim, size); }
 static void *rbf_tps_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_TPS, dim, size); }
+static void *rbf_wendland_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_WENDLAND, dim, size); }
 
 static void rbf_release_devices(rbf_state *st)
 {
@@ -558,7 +559,10 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
   int s = rbf_prepare_devices(interp, st);
   if (s) return s;
   gsl_sinterp_hip_ctx *c = st->ctx;
-  st->eps = interp->shape > 0 ? interp->shape : 2.0 * pow((double)n, 1.0 / (double)dim);
+  /* default shape: Gaussian eps = 2 N^(1/d) (the C-configurations); Wendland: support radius of eight mean
+     spacings of a unit box, eps = N^(1/d) / 8 */
+  st->eps = interp->shape > 0 ? interp->shape
+            : (st->kind == GSL_SINTERP_RBF_WENDLAND ? 0.125 : 2.0) * pow((double)n, 1.0 / (double)dim);
 
   double *h_x = (double *)malloc(n * dim * sizeof(double));
   double *h_f = (double *)malloc(n * sizeof(double));
@@ -766,6 +770,8 @@ static int simplex_eval_resident(const gsl_sinterp *interp, const double *d_y, s
 static const gsl_sinterp_type gauss_type = {"rbf-gaussian", 1, &rbf_gauss_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
 static const gsl_sinterp_type tps_type = {"rbf-thin-plate-spline", 1, &rbf_tps_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
 static const gsl_sinterp_type simplex_type = {"linear-simplex", 3, &simplex_alloc, &simplex_init, &simplex_eval_many, &simplex_eval_resident, &simplex_free};
+static const gsl_sinterp_type wendland_type = {"rbf-wendland-c2", 1, &rbf_wendland_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
+const gsl_sinterp_type *gsl_sinterp_rbf_wendland = &wendland_type;
 const gsl_sinterp_type *gsl_sinterp_rbf_gaussian = &gauss_type;
 const gsl_sinterp_type *gsl_sinterp_rbf_tps = &tps_type;
 const gsl_sinterp_type *gsl_sinterp_linear_simplex = &simplex_type;
@@ -1021,7 +1027,7 @@ int gsl_sinterp_fprintf_grid(FILE *stream, const gsl_vector *min, const gsl_vect
 /* ======================================================================== */
 static const char INTERP_MAGIC[8] = {'G', 'S', 'L', 'S', 'I', 'N', 'T', '1'};
 
-static int type_id(const gsl_sinterp_type *T) { return T == &gauss_type ? 0 : (T == &tps_type ? 1 : 2); }
+static int type_id(const gsl_sinterp_type *T) { return T == &gauss_type ? 0 : (T == &tps_type ? 1 : (T == &wendland_type ? 3 : 2)); }
 
 int gsl_sinterp_fwrite(FILE *stream, const gsl_sinterp *interp)
 {

@@ -226,6 +226,7 @@ struct gsl_sinterp_struct {
 
 extern const gsl_sinterp_type *gsl_sinterp_rbf_gaussian;
 extern const gsl_sinterp_type *gsl_sinterp_rbf_tps;
+extern const gsl_sinterp_type *gsl_sinterp_rbf_wendland;    /* compactly supported C2 kernel (README:18-26 future list) */
 extern const gsl_sinterp_type *gsl_sinterp_linear_simplex;
 
 gsl_sinterp *gsl_sinterp_alloc(const gsl_sinterp_type *T, size_t dim, size_t size);

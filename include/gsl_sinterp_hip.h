@@ -38,6 +38,9 @@ typedef struct gsl_sinterp_hip_ctx gsl_sinterp_hip_ctx;
 /* radial kernels */
 #define GSL_SINTERP_RBF_GAUSSIAN 0 /* phi(r) = exp(-(eps r)^2)                      */
 #define GSL_SINTERP_RBF_TPS 1      /* phi(r) = r^2 ln r = 0.5 r^2 ln r^2, phi(0)=0  */
+#define GSL_SINTERP_RBF_WENDLAND 2 /* phi(r) = (1 - eps r)_+^4 (4 eps r + 1): Wendland's C2 function, compact support of
+                                      radius 1/eps, positive definite for dim <= 3 (the reference's README:18-26 lists
+                                      compactly supported kernels as future work); Cholesky route, sweep with EXACT culling */
 
 /* ---- context / memory --------------------------------------------------- */
 int gsl_sinterp_hip_device_count(void); /* 0 when no GPU is visible */

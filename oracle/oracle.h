@@ -129,6 +129,7 @@ int oracle_output_triangulation(oracle_tree *t, const double *data, size_t tda, 
 /* ======================= RBF harness (oracle_rbf.c) ================== */
 #define ORACLE_RBF_GAUSSIAN 0   /* phi = exp(-(eps r)^2)                    */
 #define ORACLE_RBF_TPS 1        /* phi = r^2 ln r = 0.5 r^2 ln r^2, phi(0)=0 */
+#define ORACLE_RBF_WENDLAND 2   /* phi = (1 - eps r)_+^4 (4 eps r + 1)      */
 double oracle_rbf_phi(int kind, double eps, double r2);
 void oracle_rbf_fill(int kind, double eps, const double *x, size_t n, int dim, size_t tda,
                      double *phi, size_t lda);

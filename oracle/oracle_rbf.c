@@ -4,7 +4,7 @@
  * RBF interpolation is NOT implemented in the reference (README:18-26 lists it
  * as future work), so this harness is the composition SURVEY.md 3.3/3.4 fixes:
  *   fill   Phi_ij = phi(|x_i - x_j|) with libm exp/log           (no reference code)
- *   solve  Gaussian: gsl_linalg_cholesky_decomp1 + _svx          (linalg/cholesky.c:88,163)
+ *   solve  Gaussian, Wendland: gsl_linalg_cholesky_decomp1 + _svx (linalg/cholesky.c:88,163)
  *          TPS:      gsl_linalg_LU_decomp + _svx (not SPD)       (linalg/lu.c:59,166)
  *   eval   s(y) = sum_j w_j phi(|y - x_j|), j ascending          (no reference code)
  * The RBF kernels are therefore "parity unpinned" by any reference test; the
@@ -18,6 +18,11 @@
 double oracle_rbf_phi(int kind, double eps, double r2)
 {
   if (kind == ORACLE_RBF_GAUSSIAN) return exp(-(eps * eps) * r2);
+  if (kind == ORACLE_RBF_WENDLAND) {                 /* (1 - eps r)_+^4 (4 eps r + 1), Wendland C2 */
+    const double t = eps * sqrt(r2), u = 1.0 - t;
+    if (u <= 0.0) return 0.0;
+    return (u * u) * (u * u) * (4.0 * t + 1.0);
+  }
   if (r2 == 0.0) return 0.0;
   return 0.5 * r2 * log(r2);
 }
@@ -45,7 +50,7 @@ int oracle_rbf_solve(int kind, double eps, const double *x, size_t n, int dim, s
   oracle_rbf_fill(kind, eps, x, n, dim, tda, phi, n);
   memcpy(w, f, n * sizeof(double));
   int status;
-  if (kind == ORACLE_RBF_GAUSSIAN) {
+  if (kind != ORACLE_RBF_TPS) {                      /* positive definite kernels: Gaussian, Wendland */
     status = oracle_cholesky_decomp1(n, phi, n);
     if (status == ORACLE_SUCCESS) status = oracle_cholesky_svx(n, phi, n, w);
   } else {

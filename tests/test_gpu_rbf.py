@@ -257,3 +257,67 @@ def test_repeated_init_on_one_context(pkg, orc, kind, dim, n):
             ctx.rbf_eval(kind, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(dev(y)), 500, dim, ptr(d_s))
             ctx.sync()
             assert relerr(d_s.cpu().numpy(), orc.rbf_eval(kind, eps, x, want, y)) < TOL
+
+
+# ---- compactly supported kernel (Wendland C2; the reference's README:18-26 future list) ------------------------
+@pytest.mark.parametrize("dim,n", [(2, 600), (3, 700), (1, 130)])
+def test_wendland_fill_matches_oracle(pkg, orc, dim, n):
+    x = orc.synth_centres(n, dim)
+    eps = 0.125 * n ** (1.0 / dim)
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_x = dev(x)
+    phi = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    ctx.rbf_fill(pkg.capi.RBF_WENDLAND, eps, ptr(d_x), n, dim, dim, ptr(phi), n)
+    got = phi.cpu().numpy()
+    want = orc.rbf_fill(2, eps, x)
+    assert np.abs(got - want).max() <= 4e-15
+    assert np.array_equal(got, got.T) and (np.diag(got) == 1.0).all()
+    assert np.array_equal(got == 0.0, want == 0.0)                   # the support is cut at exactly the same pairs
+
+
+@pytest.mark.parametrize("dim,n,m", [(2, 900, 6000), (3, 1500, 5000), (2, 4096, 20000), (1, 300, 700)])
+def test_wendland_facade_matches_oracle(pkg, orc, dim, n, m):
+    """alloc / init (Cholesky route) / eval through the facade; n >= 1024 takes the culled sweep, whose culling is
+    exact for a compactly supported kernel (dropped terms are 0), the others the plain one."""
+    x = orc.synth_centres(n, dim)
+    f = orc.synth_response(x)
+    y = np.ascontiguousarray(np.concatenate([orc.synth_targets(0, m - 4, dim), x[:2], 3.0 + orc.synth_targets(1, 2, dim)]))
+    eps = 0.125 * n ** (1.0 / dim)                                   # the facade's default shape for this kernel
+    s = pkg.Sinterp("wendland", dim, n, 0)
+    assert s.init(x, f) == 0 and s.route() == 1
+    st, got, _ = s.eval_many(y)
+    assert st == 0
+    w = orc.rbf_solve(2, eps, x, f)
+    want = orc.rbf_eval(2, eps, x, w, y)
+    assert relerr(got, want) < TOL
+    assert (got[-2:] == 0.0).all()                                   # targets outside every support: exactly 0
+    st, gw = s.weights()
+    assert st == 0 and relerr(gw, w) < 1e-8
+    st, at_centres, _ = s.eval_many(x)
+    assert relerr(at_centres, f) < 1e-9
+    # bit-reproducible, and independent of how the batch is split
+    st, again, _ = s.eval_many(y)
+    assert np.array_equal(got, again)
+    st, part, _ = s.eval_many(np.ascontiguousarray(y[: m // 3]))
+    assert np.array_equal(part, got[: m // 3])
+    # NaN targets propagate
+    st, nanv, _ = s.eval_many(np.full((1, dim), np.nan))
+    assert np.isnan(nanv[0])
+
+
+def test_wendland_checkpoint_round_trip(pkg, orc, tmp_path):
+    n, dim = 500, 2
+    x = orc.synth_centres(n, dim)
+    f = orc.synth_response(x)
+    y = orc.synth_targets(2, 1000, dim)
+    a = pkg.Sinterp("wendland", dim, n, 0)
+    assert a.init(x, f) == 0
+    st, va, _ = a.eval_many(y)
+    path = str(tmp_path / "wendland.bin")
+    assert a.fwrite(path) == 0
+    b = pkg.Sinterp("wendland", dim, n, 0)
+    assert b.fread(path) == 0
+    st, vb, _ = b.eval_many(y)
+    assert st == 0 and np.array_equal(va, vb)
+    c = pkg.Sinterp("gaussian", dim, n, 0)                           # a checkpoint of another kernel is refused
+    assert c.fread(path) != 0

@@ -251,3 +251,23 @@ def test_lu_refine_keeps_the_known_answers(orc, n):
         assert st == 0 and st2 == 0
         tol = spec["lu_eps_mult"] * EPS if "lu_eps_mult" in spec else spec["lu_abs_tol"]
         assert all(rel_ok(xr[i], spec["solution"][i], tol) for i in range(n)), (name, n, xr)
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_wendland_kernel_properties(orc, dim):
+    """The compactly supported kernel of the oracle (parity unpinned by any reference file: README:18-26 lists such
+    kernels as future work): phi(0) = 1, exactly 0 from the support radius on, the closed form inside, and a kernel
+    matrix the reference's Cholesky accepts (positive definite for dim <= 3) whose solve reproduces the data."""
+    n = 150
+    x = orc.synth_centres(n, dim)
+    eps = 0.25 * n ** (1.0 / dim)
+    phi = orc.rbf_fill(2, eps, x)
+    r = np.sqrt(((x[:, None, :] - x[None, :, :]) ** 2).sum(axis=2))
+    t = eps * r
+    want = np.where(t < 1.0, (1.0 - t) ** 4 * (4.0 * t + 1.0), 0.0)
+    assert np.allclose(phi, want, rtol=0, atol=1e-14) and (np.diag(phi) == 1.0).all()
+    assert (phi[t >= 1.0 + 1e-12] == 0.0).all() and np.array_equal(phi, phi.T)
+    assert np.linalg.eigvalsh(phi).min() > 0.0
+    f = orc.synth_response(x)
+    w = orc.rbf_solve(2, eps, x, f)
+    assert np.abs(orc.rbf_eval(2, eps, x, w, x) - f).max() < 1e-10 * max(1.0, np.abs(f).max())
