@@ -54,7 +54,7 @@ bbox_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, unsign
     if ((threadIdx.x & 63) == 0) { s_lo[c][threadIdx.x >> 6] = lo[c]; s_hi[c][threadIdx.x >> 6] = hi[c]; }
   }
   __syncthreads();
-  if (threadIdx.x < dim) {
+  if ((int)threadIdx.x < dim) {
     const int c = threadIdx.x;
     unsigned long long l = s_lo[c][0], h = s_hi[c][0];
     for (int w = 1; w < 4; w++) { l = s_lo[c][w] < l ? s_lo[c][w] : l; h = s_hi[c][w] > h ? s_hi[c][w] : h; }
