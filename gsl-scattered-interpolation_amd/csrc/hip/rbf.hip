@@ -266,17 +266,23 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
    one of the per-centre early-out (term < 2^-72 of the kernel maximum), applied to a lower bound
    of the distance, so only terms below that bound are dropped; the summation order is the (fixed)
    Morton order of the centres instead of their input order. */
-#define CT 128
-#define CULL_MAX_TILES 4096
+#ifndef CT
+#define CT 32      /* 128 until round 2.  A target tests every centre of the tiles its workgroup keeps; smaller tiles hug
+                      the cut-off disc more closely.  Sweep + target sort, ms: C4 (2-D, N = 8192, M = 1e7) 2.41 / 1.97 /
+                      1.73 / 1.58 and C3 (3-D, N = 16384, M = 1e6) 1.96 / 1.75 / 1.70 / 1.74 for CT = 128 / 64 / 32 / 16 */
+#endif
+#define CULL_MAX_TILES 8192
 
+#define CT_THREADS (CT < 64 ? 64 : CT)
 template <int DIM>
-__global__ void __launch_bounds__(CT)
+__global__ void __launch_bounds__(CT_THREADS)
 centre_pack_kernel(const double *__restrict__ x, size_t n, size_t xtda, const double *__restrict__ w,
                    const int *__restrict__ perm, double *__restrict__ xs, double *__restrict__ tbox)
 {
-  __shared__ double s_lo[DIM][2], s_hi[DIM][2];
+  constexpr int NW = (CT + 63) / 64;
+  __shared__ double s_lo[DIM][NW], s_hi[DIM][NW];
   const size_t i = (size_t)blockIdx.x * CT + threadIdx.x;
-  const bool ok = i < n;
+  const bool ok = threadIdx.x < CT && i < n;
   double v[DIM];
   if (ok) {
     const size_t j = (size_t)perm[i];
@@ -293,8 +299,10 @@ centre_pack_kernel(const double *__restrict__ x, size_t n, size_t xtda, const do
   __syncthreads();
   if (threadIdx.x < DIM) {
     const int c = threadIdx.x;
-    tbox[(size_t)blockIdx.x * (2 * DIM) + 2 * c] = fmin(s_lo[c][0], s_lo[c][1]);
-    tbox[(size_t)blockIdx.x * (2 * DIM) + 2 * c + 1] = fmax(s_hi[c][0], s_hi[c][1]);
+    double l = s_lo[c][0], h = s_hi[c][0];
+    for (int w = 1; w < NW; w++) { l = fmin(l, s_lo[c][w]); h = fmax(h, s_hi[c][w]); }
+    tbox[(size_t)blockIdx.x * (2 * DIM) + 2 * c] = l;
+    tbox[(size_t)blockIdx.x * (2 * DIM) + 2 * c + 1] = h;
   }
 }
 
@@ -418,15 +426,15 @@ static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double 
   dim3 grid((unsigned)((m + per_block - 1) / per_block));
   switch (dim) {
     case 1:
-      hipLaunchKernelGGL((centre_pack_kernel<1>), dim3(ntiles), dim3(CT), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
+      hipLaunchKernelGGL((centre_pack_kernel<1>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
       hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 1, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
     case 2:
-      hipLaunchKernelGGL((centre_pack_kernel<2>), dim3(ntiles), dim3(CT), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
+      hipLaunchKernelGGL((centre_pack_kernel<2>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
       hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 2, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
     default:
-      hipLaunchKernelGGL((centre_pack_kernel<3>), dim3(ntiles), dim3(CT), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
+      hipLaunchKernelGGL((centre_pack_kernel<3>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
       hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 3, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
   }
