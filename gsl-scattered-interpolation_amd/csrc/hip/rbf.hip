@@ -308,19 +308,23 @@ centre_pack_kernel(const double *__restrict__ x, size_t n, size_t xtda, const do
 
 /* KIND = Gaussian: cut-off 2^-72 of the kernel maximum (coef = -eps^2 log2 e); KIND = Wendland: the support
    radius itself (coef = eps), so culling drops terms that are exactly 0 */
+#ifndef CULL_THREADS
+#define CULL_THREADS 128   /* 256 / 128 / 64 threads: C3 sweep 1.34 / 1.26 / 1.27 ms, C4 1.71 ms throughout */
+#endif
 template <int KIND, int DIM, int TPT>
-__global__ void __launch_bounds__(EV_THREADS)
+__global__ void __launch_bounds__(CULL_THREADS)
 rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n, const double *__restrict__ tbox, unsigned ntiles,
                            const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm)
 {
   __shared__ double s_t0[TBL_N];
   __shared__ __attribute__((aligned(16))) double s_c[CT * (DIM + 1)];
-  __shared__ double s_blo[DIM][4], s_bhi[DIM][4];
+  constexpr int NWV = CULL_THREADS / 64;
+  __shared__ double s_blo[DIM][NWV], s_bhi[DIM][NWV];
   __shared__ unsigned long long s_mask[CULL_MAX_TILES / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < TBL_N; i += EV_THREADS) s_t0[i] = g_rbf_tables.exp2_frac[i];
+  for (int i = tid; i < TBL_N; i += CULL_THREADS) s_t0[i] = g_rbf_tables.exp2_frac[i];
 
-  const size_t k0 = (((size_t)blockIdx.x * EV_THREADS) + tid) * TPT;
+  const size_t k0 = (((size_t)blockIdx.x * CULL_THREADS) + tid) * TPT;
   size_t kidx[TPT];
   double yy[TPT][DIM], acc[TPT];
 #pragma unroll
@@ -344,12 +348,13 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
   double blo[DIM], bhi[DIM];
 #pragma unroll
   for (int c = 0; c < DIM; c++) {
-    blo[c] = fmin(fmin(s_blo[c][0], s_blo[c][1]), fmin(s_blo[c][2], s_blo[c][3]));
-    bhi[c] = fmax(fmax(s_bhi[c][0], s_bhi[c][1]), fmax(s_bhi[c][2], s_bhi[c][3]));
+    blo[c] = s_blo[c][0]; bhi[c] = s_bhi[c][0];
+#pragma unroll
+    for (int w = 1; w < NWV; w++) { blo[c] = fmin(blo[c], s_blo[c][w]); bhi[c] = fmax(bhi[c], s_bhi[c][w]); }
   }
   /* tiles within the cut-off of the box: one bit per tile */
   const unsigned nmask = (ntiles + 63) / 64;
-  for (unsigned base = 0; base < ntiles; base += EV_THREADS) {
+  for (unsigned base = 0; base < ntiles; base += CULL_THREADS) {
     const unsigned t = base + tid;
     bool keep = false;
     if (t < ntiles) {
@@ -375,7 +380,7 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
       const size_t c0 = (size_t)t * CT;
       const int cnt = (int)((n - c0) < (size_t)CT ? (n - c0) : (size_t)CT);
       __syncthreads();
-      for (int e = tid; e < cnt * (DIM + 1); e += EV_THREADS) s_c[e] = xs[c0 * (DIM + 1) + e];
+      for (int e = tid; e < cnt * (DIM + 1); e += CULL_THREADS) s_c[e] = xs[c0 * (DIM + 1) + e];
       __syncthreads();
 #pragma unroll 2
       for (int e = 0; e < cnt; e++) {
@@ -422,20 +427,20 @@ static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double 
   st = sinterp_centbuf(ctx, (n * (size_t)(dim + 1) + (size_t)ntiles * 2 * dim) * sizeof(double), &buf);
   if (st) return st;
   double *xs = (double *)buf, *tbox = xs + n * (size_t)(dim + 1);
-  const size_t per_block = (size_t)EV_THREADS * TPT;
+  const size_t per_block = (size_t)CULL_THREADS * TPT;
   dim3 grid((unsigned)((m + per_block - 1) / per_block));
   switch (dim) {
     case 1:
       hipLaunchKernelGGL((centre_pack_kernel<1>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 1, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 1, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
     case 2:
       hipLaunchKernelGGL((centre_pack_kernel<2>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 2, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 2, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
     default:
       hipLaunchKernelGGL((centre_pack_kernel<3>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 3, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 3, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
   }
   LAUNCH_CHECK(ctx);
@@ -536,6 +541,10 @@ extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, doub
      batch split into shards -- or a single-point call -- returns the bits of the one-batch result): it is chosen
      by N only; small batches simply run the culled kernel without the target sort. */
   if (local && !no_cull && n >= 1024 && (n + CT - 1) / CT <= CULL_MAX_TILES) {
+    /* 3-D: one target per lane also for large batches -- a workgroup's 256 targets span half the box of 512, and
+       in three dimensions that removes more tested-and-rejected centres than the second accumulator chain gains
+       (C3 sweep 1.70 -> 1.34 ms; 2-D C4: 1.74 vs 1.77 ms, unchanged) */
+    const bool small = m < (size_t)CULL_THREADS * 2 * 512 || dim == 3;
     if (kind == GSL_SINTERP_RBF_WENDLAND)
       return small ? launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
                    : launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
