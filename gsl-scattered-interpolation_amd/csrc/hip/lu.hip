@@ -113,18 +113,24 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
     }
   }
 
+  const unsigned n32 = (unsigned)n, j032 = (unsigned)j0;       /* n < 2^31 (ipiv is int) */
 #pragma unroll
   for (int j = 0; j < LB; j++) {
     if (j < w) {                                    /* w is uniform */
-      const unsigned col = (unsigned)(j0 + j);
+      const unsigned col = j032 + (unsigned)j;
+      /* row indices are re-derived from a laundered thread id in every column step: kept live across the eight
+         unrolled steps (with the 64 panel registers of R = 4) they were spilled and reloaded on the dependent path */
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const unsigned rbase = j032 + (unsigned)tl;
       /* pivot search: max |a|, smallest row on ties (lu.c:82-93) */
       double best = -1.0;
       unsigned brow = 0xffffffffu;
 #pragma unroll
       for (int s = 0; s < R; s++) {
-        const size_t row = j0 + tid + (size_t)LU_THREADS * s;
+        const unsigned row = rbase + (unsigned)LU_THREADS * s;
         const double v = fabs(a[s][j]);
-        if (row < n && row >= col && v > best) { best = v; brow = (unsigned)row; }
+        if (row < n32 && row >= col && v > best) { best = v; brow = row; }
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
@@ -145,15 +151,15 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       if (piv == 0xffffffffu) piv = col;            /* NaN column: keep the diagonal row */
       if (tid == 0) ipiv[col] = (int)piv;
       /* publish the pivot row and the current row, then swap them */
-      const unsigned own_p = (piv - (unsigned)j0) % LU_THREADS, slot_p = (piv - (unsigned)j0) / LU_THREADS;
+      const unsigned own_p = (piv - j032) % LU_THREADS, slot_p = (piv - j032) / LU_THREADS;
       const unsigned own_c = (unsigned)j % LU_THREADS;       /* col - j0 = j < 1024: slot 0 */
 #pragma unroll
       for (int s = 0; s < R; s++)
-        if ((unsigned)tid == own_p && (unsigned)s == slot_p) {
+        if ((unsigned)tl == own_p && (unsigned)s == slot_p) {
 #pragma unroll
           for (int k = 0; k < LB; k++) s_prow[k] = a[s][k];
         }
-      if ((unsigned)tid == own_c) {
+      if ((unsigned)tl == own_c) {
 #pragma unroll
         for (int k = 0; k < LB; k++) s_crow[k] = a[0][k];
       }
@@ -161,11 +167,11 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       if (piv != col) {
 #pragma unroll
         for (int s = 0; s < R; s++)
-          if ((unsigned)tid == own_p && (unsigned)s == slot_p) {
+          if ((unsigned)tl == own_p && (unsigned)s == slot_p) {
 #pragma unroll
             for (int k = 0; k < LB; k++) a[s][k] = s_crow[k];
           }
-        if ((unsigned)tid == own_c) {
+        if ((unsigned)tl == own_c) {
 #pragma unroll
           for (int k = 0; k < LB; k++) a[0][k] = s_prow[k];
         }
@@ -174,8 +180,8 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       if (ajj != 0.0) {                              /* lu.c:105 */
 #pragma unroll
         for (int s = 0; s < R; s++) {
-          const size_t row = j0 + tid + (size_t)LU_THREADS * s;
-          if (row < n && row > col) {
+          const unsigned row = rbase + (unsigned)LU_THREADS * s;
+          if (row < n32 && row > col) {
             const double l = a[s][j] / ajj;
             a[s][j] = l;
 #pragma unroll
