@@ -90,19 +90,19 @@ lu_base_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int w, i
    in the VGPRs of ONE workgroup for the duration of its 8 column steps, so a
    column step costs two workgroup barriers instead of round trips through L2.
    Row i of the panel belongs to thread (i - j0) % 1024, slot (i - j0) / 1024. */
-template <int R>
-__global__ void __launch_bounds__(LU_THREADS)
+template <int R, int NTH = LU_THREADS>
+__global__ void __launch_bounds__(NTH)
 lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int w, int *__restrict__ ipiv)
 {
-  __shared__ double s_val[LU_THREADS / 64];
-  __shared__ unsigned int s_row[LU_THREADS / 64];
+  __shared__ double s_val[NTH / 64];
+  __shared__ unsigned int s_row[NTH / 64];
   __shared__ double s_prow[LB], s_crow[LB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   double a[R][LB];
 #pragma unroll
   for (int s = 0; s < R; s++) {
-    const size_t row = j0 + tid + (size_t)LU_THREADS * s;
+    const size_t row = j0 + tid + (size_t)NTH * s;
     const double *p = A + row * lda + j0;
     if (row < n && w == LB && ((((uintptr_t)p) & 15) == 0)) {
 #pragma unroll
@@ -128,7 +128,7 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       unsigned brow = 0xffffffffu;
 #pragma unroll
       for (int s = 0; s < R; s++) {
-        const unsigned row = rbase + (unsigned)LU_THREADS * s;
+        const unsigned row = rbase + (unsigned)NTH * s;
         const double v = fabs(a[s][j]);
         if (row < n32 && row >= col && v > best) { best = v; brow = row; }
       }
@@ -143,7 +143,7 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       double bv = s_val[0];
       unsigned piv = s_row[0];
 #pragma unroll
-      for (int k = 1; k < LU_THREADS / 64; k++) {
+      for (int k = 1; k < NTH / 64; k++) {
         const double ov = s_val[k];
         const unsigned orow = s_row[k];
         if (ov > bv || (ov == bv && orow < piv)) { bv = ov; piv = orow; }
@@ -151,8 +151,8 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       if (piv == 0xffffffffu) piv = col;            /* NaN column: keep the diagonal row */
       if (tid == 0) ipiv[col] = (int)piv;
       /* publish the pivot row and the current row, then swap them */
-      const unsigned own_p = (piv - j032) % LU_THREADS, slot_p = (piv - j032) / LU_THREADS;
-      const unsigned own_c = (unsigned)j % LU_THREADS;       /* col - j0 = j < 1024: slot 0 */
+      const unsigned own_p = (piv - j032) % NTH, slot_p = (piv - j032) / NTH;
+      const unsigned own_c = (unsigned)j % NTH;       /* col - j0 = j < 1024: slot 0 */
 #pragma unroll
       for (int s = 0; s < R; s++)
         if ((unsigned)tl == own_p && (unsigned)s == slot_p) {
@@ -180,13 +180,15 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       if (ajj != 0.0) {                              /* lu.c:105 */
 #pragma unroll
         for (int s = 0; s < R; s++) {
-          const unsigned row = rbase + (unsigned)LU_THREADS * s;
+          const unsigned row = rbase + (unsigned)NTH * s;
           if (row < n32 && row > col) {
             const double l = a[s][j] / ajj;
             a[s][j] = l;
 #pragma unroll
             for (int k = j + 1; k < LB; k++) a[s][k] = a[s][k] - l * s_prow[k];
           }
+          /* one row at a time: interleaved, the IEEE divide expansions of all R rows keep ~10 temporaries each live */
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       /* s_val / s_prow are rewritten only after the next iteration's first barrier
@@ -196,7 +198,7 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
 
 #pragma unroll
   for (int s = 0; s < R; s++) {
-    const size_t row = j0 + tid + (size_t)LU_THREADS * s;
+    const size_t row = j0 + tid + (size_t)NTH * s;
     if (row >= n) continue;
     double *p = A + row * lda + j0;
     if (w == LB && ((((uintptr_t)p) & 15) == 0)) {
@@ -535,8 +537,16 @@ static int lu_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, s
       hipLaunchKernelGGL(lu_base_reg_kernel<1>, dim3(1), dim3(LU_THREADS), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
     else if (rows <= (size_t)LU_THREADS * 2)
       hipLaunchKernelGGL(lu_base_reg_kernel<2>, dim3(1), dim3(LU_THREADS), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
-    else if (rows <= (size_t)LU_THREADS * 4)
-      hipLaunchKernelGGL(lu_base_reg_kernel<4>, dim3(1), dim3(LU_THREADS), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
+    else if (rows <= (size_t)LU_THREADS * 4) {
+      /* 512 threads x 8 rows: with 1024 threads the 64 panel registers of 4 rows per thread do not fit the 128-VGPR
+         budget of a 16-wave workgroup (scratch on the dependent path), and the per-wave work of a column step
+         (reductions, pivot-row exchange, scalar control) is paid by twice as many waves */
+      static const int th = getenv("GSL_SINTERP_LU_BASE_THREADS") ? atoi(getenv("GSL_SINTERP_LU_BASE_THREADS")) : 512;
+      if (th == 1024)
+        hipLaunchKernelGGL(lu_base_reg_kernel<4>, dim3(1), dim3(LU_THREADS), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
+      else
+        hipLaunchKernelGGL((lu_base_reg_kernel<8, 512>), dim3(1), dim3(512), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
+    }
     else   /* taller than the register file of one CU: panel stays in L2 */
       hipLaunchKernelGGL(lu_base_kernel, dim3(1), dim3(LU_THREADS), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
     LAUNCH_CHECK(ctx);
