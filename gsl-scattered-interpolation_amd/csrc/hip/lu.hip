@@ -140,14 +140,19 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       }
       if (lane == 0) { s_val[wave] = best; s_row[wave] = brow; }
       __syncthreads();
-      double bv = s_val[0];
-      unsigned piv = s_row[0];
+      /* second level: lane k of every wave takes wave k's candidate, a 4-step butterfly finishes it (one LDS round
+         trip + shuffles; read one after the other by a scalarised loop the NTH / 64 candidates cost 16 dependent LDS
+         round trips per column step).  Same comparator: larger |a|, smaller row on ties; candidates are never NaN */
+      constexpr int NWV = NTH / 64;
+      double bv = lane < NWV ? s_val[lane] : -1.0;
+      unsigned piv = lane < NWV ? s_row[lane] : 0xffffffffu;
 #pragma unroll
-      for (int k = 1; k < NTH / 64; k++) {
-        const double ov = s_val[k];
-        const unsigned orow = s_row[k];
+      for (int off = NWV / 2; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const unsigned orow = __shfl_xor(piv, off);
         if (ov > bv || (ov == bv && orow < piv)) { bv = ov; piv = orow; }
       }
+      piv = (unsigned)__builtin_amdgcn_readfirstlane((int)piv);
       if (piv == 0xffffffffu) piv = col;            /* NaN column: keep the diagonal row */
       if (tid == 0) ipiv[col] = (int)piv;
       /* publish the pivot row and the current row, then swap them */
