@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0, 0, 0, 0, 0]])
-@pytest.mark.parametrize("kind,dim,n,m", [("gaussian", 2, 1500, 20011), ("tps", 2, 900, 5003), ("gaussian", 3, 1100, 3)])
+@pytest.mark.parametrize("kind,dim,n,m", [("gaussian", 2, 1500, 20011), ("tps", 2, 900, 5003), ("gaussian", 3, 1100, 3),
+                                          ("wendland", 2, 1300, 9001)])
 def test_facade_rbf_sharded_equals_single_device(pkg, orc, devices, kind, dim, n, m):
     x = orc.synth_centres(n, dim)
     f = orc.synth_response(x)
@@ -43,8 +44,8 @@ def test_facade_rbf_sharded_equals_single_device(pkg, orc, devices, kind, dim, n
     st, got2, _ = multi.eval_many(y[: m // 2 + 1])
     assert st == 0 and np.array_equal(bits(got2), bits(want[: m // 2 + 1]))
     # oracle parity of the sharded result (north star tolerance)
-    kid = 0 if kind == "gaussian" else 1
-    eps = orc.gaussian_eps(n, dim)
+    kid = {"gaussian": 0, "tps": 1, "wendland": 2}[kind]
+    eps = 0.125 * n ** (1.0 / dim) if kind == "wendland" else orc.gaussian_eps(n, dim)
     ref = orc.rbf_eval(kid, eps, x, orc.rbf_solve(kid, eps, x, f), y)
     assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
 
