@@ -132,6 +132,8 @@ SIGNATURES = {
     "gsl_sinterp_hip_pcholesky_svx": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "gsl_sinterp_hip_rbf_solve_ex": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _i, _pd, _pi]),
     "gsl_sinterp_hip_rbf_eval": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp]),
+    "gsl_sinterp_hip_rbf_eval_model": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp, C.c_uint64]),
+    "gsl_sinterp_hip_ctx_device": (_i, [_vp]),
     "gsl_sinterp_hip_rbf_solve": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _pi]),
     "gsl_sinterp_hip_gemm_minus": (_i, [_vp, _sz, _sz, _sz, _vp, _sz, _vp, _sz, _i, _vp, _sz, _i]),
     "gsl_sinterp_hip_grid_targets": (_i, [_vp, _d, _d, _sz, _d, _d, _sz, _vp]),
@@ -368,8 +370,13 @@ class HipContext:
     def lu_svx(self, n, d_lu, lda, d_perm, d_x):
         return lib().gsl_sinterp_hip_lu_svx(self._h, n, d_lu, lda, d_perm, d_x)
 
-    def rbf_eval(self, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s):
-        check(lib().gsl_sinterp_hip_rbf_eval(self._h, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s), self._h)
+    def rbf_eval(self, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, model_id=0):
+        """model_id != 0: the caller vouches that (d_x, d_w) do not change while it uses this id, so the sweep's
+        per-model preprocessing is cached in the context (gsl_sinterp_hip_rbf_eval_model)"""
+        check(lib().gsl_sinterp_hip_rbf_eval_model(self._h, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, model_id), self._h)
+
+    def device(self):
+        return lib().gsl_sinterp_hip_ctx_device(self._h)
 
     def cholesky_decomp2(self, n, d_a, lda, d_s):
         info = C.c_int(0)

@@ -32,6 +32,8 @@ struct gsl_sinterp_hip_ctx {
   size_t sort2_bytes;
   void *d_cent;             /* cell-ordered packed centres {x, w} + tile boxes of the Gaussian sweep */
   size_t cent_bytes;
+  /* key of the packed centres currently in d_cent (gsl_sinterp_hip_rbf_eval_model); id 0 = nothing cached */
+  struct { unsigned long long id; const void *x, *w; size_t n, xtda; int dim, kind; } cent_key;
   void *d_walk;             /* affine walk records + queue of the barycentric walk (bary.hip), rebuilt per batch */
   size_t walk_bytes;
   hipStream_t side_stream;  /* bary.hip: independent kernels of one evaluation run beside the main stream */

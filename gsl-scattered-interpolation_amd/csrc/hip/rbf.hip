@@ -418,11 +418,18 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
 
 template <int KIND, int TPT>
 static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x, size_t n, int dim, size_t xtda, const double *d_w,
-                            const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm)
+                            const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm, unsigned long long model_id)
 {
+  /* the packed centres depend on the model only: reuse them when the caller vouches for the model (model_id != 0) */
+  const bool cached = model_id != 0 && ctx->cent_key.id == model_id && ctx->cent_key.x == d_x && ctx->cent_key.w == d_w &&
+                      ctx->cent_key.n == n && ctx->cent_key.xtda == xtda && ctx->cent_key.dim == dim && ctx->cent_key.kind == KIND;
   int *d_cperm = NULL;
-  int st = sinterp_sort_centres(ctx, d_x, n, xtda, dim, 8, &d_cperm);
-  if (st) return st;
+  int st = ST_SUCCESS;
+  if (!cached) {
+    ctx->cent_key.id = 0;
+    st = sinterp_sort_centres(ctx, d_x, n, xtda, dim, 8, &d_cperm);
+    if (st) return st;
+  }
   const unsigned ntiles = (unsigned)((n + CT - 1) / CT);
   void *buf = NULL;
   st = sinterp_centbuf(ctx, (n * (size_t)(dim + 1) + (size_t)ntiles * 2 * dim) * sizeof(double), &buf);
@@ -432,19 +439,23 @@ static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double 
   dim3 grid((unsigned)((m + per_block - 1) / per_block));
   switch (dim) {
     case 1:
-      hipLaunchKernelGGL((centre_pack_kernel<1>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
+      if (!cached) hipLaunchKernelGGL((centre_pack_kernel<1>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
       hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 1, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
     case 2:
-      hipLaunchKernelGGL((centre_pack_kernel<2>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
+      if (!cached) hipLaunchKernelGGL((centre_pack_kernel<2>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
       hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 2, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
     default:
-      hipLaunchKernelGGL((centre_pack_kernel<3>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
+      if (!cached) hipLaunchKernelGGL((centre_pack_kernel<3>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
       hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 3, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
       break;
   }
   LAUNCH_CHECK(ctx);
+  if (model_id != 0 && !cached) {
+    ctx->cent_key.id = model_id; ctx->cent_key.x = d_x; ctx->cent_key.w = d_w; ctx->cent_key.n = n; ctx->cent_key.xtda = xtda;
+    ctx->cent_key.dim = dim; ctx->cent_key.kind = KIND;
+  }
   return ST_SUCCESS;
 }
 
@@ -517,6 +528,13 @@ extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, doub
                                         int dim, size_t xtda, const double *d_w, const double *d_y, size_t m,
                                         size_t ytda, double *d_s)
 {
+  return gsl_sinterp_hip_rbf_eval_model(ctx, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, 0ULL);
+}
+
+extern "C" int gsl_sinterp_hip_rbf_eval_model(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
+                                              int dim, size_t xtda, const double *d_w, const double *d_y, size_t m,
+                                              size_t ytda, double *d_s, unsigned long long model_id)
+{
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && ytda >= (size_t)dim, ST_EINVAL);
@@ -547,10 +565,10 @@ extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, doub
        (C3 sweep 1.70 -> 1.34 ms; 2-D C4: 1.74 vs 1.77 ms, unchanged) */
     const bool small = m < (size_t)CULL_THREADS * 2 * 512 || dim == 3;
     if (kind == GSL_SINTERP_RBF_WENDLAND)
-      return small ? launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
-                   : launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
-    return small ? launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
-                 : launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
+      return small ? launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, model_id)
+                   : launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, model_id);
+    return small ? launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, model_id)
+                 : launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, model_id);
   }
   if (kind == GSL_SINTERP_RBF_WENDLAND)
     return small ? launch_eval<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)

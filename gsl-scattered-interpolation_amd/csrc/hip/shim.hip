@@ -99,6 +99,8 @@ extern "C" const char *gsl_sinterp_hip_last_error(const gsl_sinterp_hip_ctx *ctx
   return ctx ? ctx->err : "no HIP context (no usable gfx950 device?)";
 }
 
+extern "C" int gsl_sinterp_hip_ctx_device(const gsl_sinterp_hip_ctx *ctx) { return ctx ? ctx->device : -1; }
+
 extern "C" int gsl_sinterp_hip_sync(gsl_sinterp_hip_ctx *ctx)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);

@@ -228,7 +228,10 @@ int sinterp_sort_targets(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
    sweep must see each cell's centres in ORIGINAL index order (fixed summation order).  One thread per centre k:
    its place inside the run is the number of run members with a smaller index -- a rank sort, no serial pass
    (the round-1 kernel sorted every run with one thread by insertion in global memory: 196 us at N = 16384 for a
-   few KB of data, 9 % of C3's sweep).  A degenerate cell (thousands of centres) keeps the scatter order. */
+   few KB of data, 9 % of C3's sweep).  Every cell is ranked, whatever its size: a heavily clustered cloud (or one far
+   outlier stretching the bounding box) puts thousands of centres into one cell, and leaving such a cell in scatter
+   order made the culled sum's order -- hence its last bits -- vary run to run and between the members of a device
+   group.  The loop is O(cell size) per centre; one cell holding all N = 16384 centres costs ~1 ms once per model. */
 __global__ void __launch_bounds__(256)
 cell_rank_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ slot, const unsigned *__restrict__ offset,
                  const int *__restrict__ perm_in, int *__restrict__ perm_out, size_t n)
@@ -236,11 +239,8 @@ cell_rank_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict
   const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
   const unsigned c = cellid[k], b = offset[c], e = offset[c + 1];
-  unsigned rank = slot[k];
-  if (e - b <= 2048u) {
-    rank = 0;
-    for (unsigned j = b; j < e; j++) rank += (unsigned)(perm_in[j] < (int)k);
-  }
+  unsigned rank = 0;
+  for (unsigned j = b; j < e; j++) rank += (unsigned)(perm_in[j] < (int)k);
   perm_out[b + rank] = (int)k;
 }
 

@@ -20,6 +20,7 @@
 #include "gsl_sinterp.h"
 #include <math.h>
 #include <stdint.h>
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -194,7 +195,10 @@ simplex_tree *simplex_tree_fread(FILE *stream)
   if (fread(head, sizeof head[0], 6, stream) != 6 || head[0] != 1)
     GSL_ERROR_NULL("simplex_tree_fread: unsupported checkpoint version", GSL_EFAILED);
   const int dim = head[1], n = head[2], n_points = head[3], max_points = head[4];
-  if (dim != 2 || n < 1 || n_points < 0 || max_points < n_points)
+  /* a triangulation of p points has at most 9p + 8 history nodes here (alloc's own estimate, linear_simplex.c:63):
+     an 8-byte corrupt header must not turn into gigabytes of node_alloc or an int overflow in 9 * max_points */
+  if (dim != 2 || n < 1 || n_points < 0 || max_points < n_points || max_points > INT_MAX / 27 ||
+      (long long)n > 9LL * max_points + 8)
     GSL_ERROR_NULL("simplex_tree_fread: corrupt header", GSL_EFAILED);
   simplex_tree *tree = simplex_tree_alloc(dim, max_points);
   if (!tree) return NULL;
@@ -209,11 +213,15 @@ simplex_tree *simplex_tree_fread(FILE *stream)
   ok = ok && fread(tree->links, sizeof(simplex_index), w, stream) == w;
   double geo[14];
   ok = ok && fread(geo, sizeof(double), 14, stream) == 14;
+  /* the shuffle must be a permutation (every row index exactly once), not merely in range */
+  unsigned char *seen = (unsigned char *)calloc((size_t)(max_points > 0 ? max_points : 1), 1);
+  ok = ok && seen != NULL;
   for (size_t i = 0; ok && i < (size_t)max_points; i++) {
     uint64_t v = 0;
-    ok = fread(&v, sizeof v, 1, stream) == 1 && v < (uint64_t)max_points;
-    if (ok) tree->shuffle->data[i] = (size_t)v;
+    ok = fread(&v, sizeof v, 1, stream) == 1 && v < (uint64_t)max_points && !seen[v];
+    if (ok) { seen[v] = 1; tree->shuffle->data[i] = (size_t)v; }
   }
+  free(seen);
   if (ok) {
     for (int k = 0; k < n && ok; k++) {
       ok = type[k] >= 0 && type[k] <= 3;
@@ -221,6 +229,10 @@ simplex_tree *simplex_tree_fread(FILE *stream)
       for (int i = 0; i < dim + 1 && ok; i++) {
         const int v = tree->pidx[(dim + 1) * k + i], l = tree->links[(dim + 1) * k + i];
         ok = v >= -(dim + 1) && v < n_points && l >= 0 && l < n;     /* indices stay inside the arrays */
+        /* children are allocated after their parent (simplex_tree_node_alloc appends), so a child link of an inner
+           node points forward: this makes the DAG acyclic and every find_leaf walk finite */
+        const int nch = type[k] == sub_dplus1_type ? dim + 1 : type[k] == sub_d_type ? dim : type[k] == sub_2_type ? 2 : 0;
+        if (ok && i < nch) ok = l > k;
       }
     }
   }

@@ -22,6 +22,7 @@
  */
 #include "gsl_sinterp.h"
 #include <math.h>
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -137,6 +138,10 @@ simplex_tree *simplex_tree_alloc(int dim, int n_points)
   tree->max_points = n_points;
 
   const int overhead = 9;                       /* linear_simplex.c:63 */
+  if (n_points > (INT_MAX / (dim + 1)) / overhead) {          /* 9 * n_points * (dim + 1) must stay an int */
+    simplex_tree_free(tree);
+    GSL_ERROR_NULL("simplex_tree: capacity too large", GSL_EINVAL);
+  }
   int cap = overhead * n_points;
   if (cap < 8) cap = 8;
   tree->max_pidx = cap * (dim + 1);
@@ -145,6 +150,11 @@ simplex_tree *simplex_tree_alloc(int dim, int n_points)
   tree->links = (simplex_index *)malloc((size_t)tree->max_links * sizeof(simplex_index));
   tree->max_simplexes = cap;
   tree->simplexes = (simplex_tree_node *)malloc((size_t)tree->max_simplexes * sizeof(simplex_tree_node));
+  /* the reference leaves these unchecked (linear_simplex.c:56-103; SURVEY.md quirk q10, marked "fix") */
+  if (!tree->seed_points || !tree->pidx || !tree->links || !tree->simplexes) {
+    simplex_tree_free(tree);
+    GSL_ERROR_NULL("failed to allocate simplex_tree arrays", GSL_ENOMEM);
+  }
 
   simplex_tree_node_alloc(tree);                /* root */
   tree->accel = simplex_tree_accel_alloc(dim);
@@ -157,11 +167,17 @@ simplex_tree *simplex_tree_alloc(int dim, int n_points)
   tree->min = gsl_vector_calloc(dim);
   tree->max = gsl_vector_calloc(dim);
   tree->shuffle = gsl_permutation_alloc(n_points);
-  gsl_permutation_init(tree->shuffle);
   tree->tmp_vec1 = gsl_vector_calloc(dim);
   tree->tmp_vec2 = gsl_vector_calloc(dim);
   tree->tmp_mat = gsl_matrix_calloc(dim, dim);
   tree->tmp_points1 = (int *)calloc(dim + 1, sizeof(int));
+  if (!tree->accel || !tree->new_simplexes || !tree->old_neighbors1 || !tree->old_neighbors2 || !tree->left_out ||
+      !tree->shift || !tree->scale || !tree->min || !tree->max || !tree->shuffle || !tree->tmp_vec1 || !tree->tmp_vec2 ||
+      !tree->tmp_mat || !tree->tmp_points1) {
+    simplex_tree_free(tree);
+    GSL_ERROR_NULL("failed to allocate simplex_tree scratch", GSL_ENOMEM);
+  }
+  gsl_permutation_init(tree->shuffle);
   return tree;
 }
 

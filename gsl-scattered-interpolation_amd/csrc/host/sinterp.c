@@ -106,9 +106,12 @@ static int shard_eval_many(shard_set *ss, size_t dim, const gsl_matrix *y, gsl_v
   }
   double *h_y = (double *)ss->h_stage, *h_s = (double *)((char *)ss->h_stage + o_s);
   int *h_l = want_leaf ? (int *)((char *)ss->h_stage + o_l) : NULL;
-  for (size_t k = 0; k < m; k++)
-    for (size_t c = 0; c < dim; c++) h_y[k * dim + c] = y->data[k * y->tda + c];
+  const int packed = y->tda == dim;
 
+  /* Staging is per shard: member r's rows are repacked (tda -> dim; one memcpy when the caller's matrix is already
+     dense) and its H2D -> sweep -> D2H chain is enqueued before shard r+1 is touched, so the host-side repack of the
+     later shards runs while the earlier members copy and compute (round 2 repacked all M rows element-wise before
+     the first copy was enqueued: tens of ms of serial host time at C4's 160 MB in front of a ~0.2 ms/GPU sweep). */
   int st = GSL_SUCCESS;
   for (int r = 0; r < ss->n && !st; r++) {
     size_t first, cnt;
@@ -124,23 +127,31 @@ static int shard_eval_many(shard_set *ss, size_t dim, const gsl_matrix *y, gsl_v
       if (st) break;
       ss->cap[r] = cnt; ss->cap_dim = 3;
     }
+    if (packed) memcpy(h_y + first * dim, y->data + first * dim, cnt * dim * sizeof(double));
+    else
+      for (size_t k = first; k < first + cnt; k++)
+        for (size_t cc = 0; cc < dim; cc++) h_y[k * dim + cc] = y->data[k * y->tda + cc];
     st = gsl_sinterp_hip_h2d_async(c, ss->d_y[r], h_y + first * dim, cnt * dim * sizeof(double));
     if (!st) st = fn(state, r, ss->d_y[r], cnt, ss->d_s[r], want_leaf ? ss->d_leaf[r] : NULL);
     if (!st) st = gsl_sinterp_hip_d2h_async(c, h_s + first, ss->d_s[r], cnt * sizeof(double));
     if (!st && want_leaf) st = gsl_sinterp_hip_d2h_async(c, h_l + first, ss->d_leaf[r], cnt * sizeof(int));
     if (st) gsl_error(gsl_sinterp_hip_last_error(c), __FILE__, __LINE__, st);
   }
+  size_t neg = 0;
   for (int r = 0; r < ss->n; r++) {                      /* always drain every member, also after a failure */
     int s2 = gsl_sinterp_hip_sync(gsl_sinterp_hip_group_ctx(ss->grp, r));
     if (!st && s2) { st = s2; gsl_error(gsl_sinterp_hip_last_error(gsl_sinterp_hip_group_ctx(ss->grp, r)), __FILE__, __LINE__, st); }
+    if (st) continue;
+    /* member r's shard goes back to the caller while the later members are still running */
+    size_t first, cnt;
+    gsl_sinterp_hip_shard_bounds(m, ss->n, r, &first, &cnt);
+    if (sv->stride == 1) memcpy(sv->data + first, h_s + first, cnt * sizeof(double));
+    else for (size_t k = first; k < first + cnt; k++) sv->data[k * sv->stride] = h_s[k];
+    if (want_leaf)
+      for (size_t k = first; k < first + cnt; k++) { neg += h_l[k] < 0; if (leaf) leaf[k] = h_l[k]; }
   }
   if (st) return st;
-  for (size_t k = 0; k < m; k++) gsl_vector_set(sv, k, h_s[k]);
-  if (want_leaf) {
-    size_t neg = 0;
-    for (size_t k = 0; k < m; k++) { neg += h_l[k] < 0; if (leaf) leaf[k] = h_l[k]; }
-    if (n_neg) *n_neg = neg;
-  }
+  if (n_neg) *n_neg = neg;
   return GSL_SUCCESS;
 }
 
@@ -513,7 +524,16 @@ typedef struct {
   /* device group (n_devices > 1): the model buffer [x | w] of every member; ss.grp owns the contexts */
   shard_set ss;
   double *m_model[SINTERP_MAX_DEVICES];
+  /* id of the model the buffers hold (fresh after every init / fread): lets the sweep keep its per-model
+     preprocessing between evaluations (gsl_sinterp_hip_rbf_eval_model) */
+  unsigned long long model_id;
 } rbf_state;
+
+static unsigned long long next_model_id(void)
+{
+  static unsigned long long counter = 0;               /* the facade is single-threaded like the reference */
+  return ++counter;
+}
 
 static void *rbf_alloc_kind(int kind, size_t dim, size_t size)
 {
@@ -561,6 +581,7 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
   gsl_sinterp_hip_ctx *c = st->ctx;
   /* default shape: Gaussian eps = 2 N^(1/d) (the C-configurations); Wendland: support radius of eight mean
      spacings of a unit box, eps = N^(1/d) / 8 */
+  st->model_id = next_model_id();                       /* the buffers are about to change */
   st->eps = interp->shape > 0 ? interp->shape
             : (st->kind == GSL_SINTERP_RBF_WENDLAND ? 0.125 : 2.0) * pow((double)n, 1.0 / (double)dim);
 
@@ -601,7 +622,8 @@ static int rbf_prepare_devices(gsl_sinterp *interp, rbf_state *st)
   const size_t n = st->n, dim = st->dim;
   const int nd = interp->n_devices > 1 ? interp->n_devices : 1;
   /* (re)build the device side when the requested device set changed */
-  int same = st->ctx != NULL && ((nd == 1 && !st->ss.grp) || (st->ss.grp && st->ss.n == nd));
+  int same = st->ctx != NULL && ((nd == 1 && !st->ss.grp && gsl_sinterp_hip_ctx_device(st->ctx) == interp->device) ||
+                                 (st->ss.grp && st->ss.n == nd));
   if (same && st->ss.grp)
     for (int r = 0; r < nd; r++) same = same && gsl_sinterp_hip_group_device(st->ss.grp, r) == interp->devices[r];
   if (!same) {
@@ -639,8 +661,8 @@ static int rbf_eval_resident(const gsl_sinterp *interp, const double *d_y, size_
   if (!st->d_w) GSL_ERROR("gsl_sinterp_eval: interpolant not initialised", GSL_EINVAL);
   /* resident buffers live on ONE device: member 0 evaluates them (shard resident targets yourself with
      gsl_sinterp_hip_shard_bounds + one interpolant per device, as bench.py does per process) */
-  HIP_TRY(gsl_sinterp_hip_rbf_eval(st->ctx, st->kind, st->eps, st->d_x, st->n, (int)st->dim, st->dim,
-                                   st->d_w, d_y, m, ytda, d_s), st->ctx);
+  HIP_TRY(gsl_sinterp_hip_rbf_eval_model(st->ctx, st->kind, st->eps, st->d_x, st->n, (int)st->dim, st->dim,
+                                         st->d_w, d_y, m, ytda, d_s, st->model_id), st->ctx);
   return GSL_SUCCESS;
 }
 
@@ -649,8 +671,8 @@ static int rbf_shard_eval(void *state, int member, const double *d_y, size_t m, 
   (void)d_leaf;
   rbf_state *st = (rbf_state *)state;
   const double *model = st->m_model[member];
-  return gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_group_ctx(st->ss.grp, member), st->kind, st->eps, model, st->n, (int)st->dim,
-                                  st->dim, model + st->n * st->dim, d_y, m, st->dim, d_s);
+  return gsl_sinterp_hip_rbf_eval_model(gsl_sinterp_hip_group_ctx(st->ss.grp, member), st->kind, st->eps, model, st->n, (int)st->dim,
+                                        st->dim, model + st->n * st->dim, d_y, m, st->dim, d_s, st->model_id);
 }
 
 static int rbf_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vector *sv, int *leaf)
@@ -676,7 +698,7 @@ static int rbf_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vec
   int s = gsl_sinterp_hip_malloc(c, (void **)&d_y, m * dim * sizeof(double));
   if (!s) s = gsl_sinterp_hip_malloc(c, (void **)&d_s, m * sizeof(double));
   if (!s) s = gsl_sinterp_hip_h2d(c, d_y, h_y, m * dim * sizeof(double));
-  if (!s) s = gsl_sinterp_hip_rbf_eval(c, st->kind, st->eps, st->d_x, st->n, (int)dim, dim, st->d_w, d_y, m, dim, d_s);
+  if (!s) s = gsl_sinterp_hip_rbf_eval_model(c, st->kind, st->eps, st->d_x, st->n, (int)dim, dim, st->d_w, d_y, m, dim, d_s, st->model_id);
   if (!s) s = gsl_sinterp_hip_d2h(c, h_s, d_s, m * sizeof(double));
   if (!s) for (size_t k = 0; k < m; k++) gsl_vector_set(sv, k, h_s[k]);
   if (!s && leaf) for (size_t k = 0; k < m; k++) leaf[k] = -1;
@@ -789,6 +811,8 @@ gsl_sinterp *gsl_sinterp_alloc(const gsl_sinterp_type *T, size_t dim, size_t siz
   interp->type = T; interp->dim = dim; interp->size = size;
   interp->device = default_device();
   interp->n_devices = env_device_list(interp->devices);   /* GSL_SINTERP_DEVICES: count or list; 0 = single device */
+  /* GSL_SINTERP_DEVICES = "1" (a COUNT of one) selects no ordinal: GSL_SINTERP_DEVICE keeps naming the device */
+  if (interp->n_devices == 1 && getenv("GSL_SINTERP_DEVICES") && !strchr(getenv("GSL_SINTERP_DEVICES"), ',')) interp->n_devices = 0;
   if (interp->n_devices >= 1) interp->device = interp->devices[0];
   else { interp->n_devices = 1; interp->devices[0] = interp->device; }
   interp->shape = 0.0; interp->init_flags = SIMPLEX_TREE_DEFAULT; interp->rng = NULL;
@@ -1109,6 +1133,7 @@ int gsl_sinterp_fread(FILE *stream, gsl_sinterp *interp)
   int s = rbf_prepare_devices(interp, st);
   if (s) { free(h); return s; }
   st->eps = eps;
+  st->model_id = next_model_id();
   s = gsl_sinterp_hip_h2d(st->ctx, st->d_x, h, cnt * sizeof(double));
   if (!s && st->ss.grp) s = gsl_sinterp_hip_group_broadcast(st->ss.grp, (void *const *)st->m_model, cnt * sizeof(double));
   if (!s) s = gsl_sinterp_hip_sync(st->ctx);

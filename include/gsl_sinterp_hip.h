@@ -51,6 +51,7 @@ int gsl_sinterp_hip_device_count(void); /* 0 when no GPU is visible */
 int gsl_sinterp_hip_ctx_create(gsl_sinterp_hip_ctx **ctx, int device, void *stream);
 int gsl_sinterp_hip_ctx_own_stream(gsl_sinterp_hip_ctx *ctx);
 void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx);
+int gsl_sinterp_hip_ctx_device(const gsl_sinterp_hip_ctx *ctx);   /* the ordinal the context was created on, -1 for NULL */
 int gsl_sinterp_hip_sync(gsl_sinterp_hip_ctx *ctx);
 const char *gsl_sinterp_hip_last_error(const gsl_sinterp_hip_ctx *ctx);
 int gsl_sinterp_hip_malloc(gsl_sinterp_hip_ctx *ctx, void **d_ptr, size_t bytes);
@@ -162,6 +163,15 @@ int gsl_sinterp_hip_pcholesky_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const doub
 int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x,
                              size_t n, int dim, size_t xtda, const double *d_w,
                              const double *d_y, size_t m, size_t ytda, double *d_s);
+
+/* The same sweep for a model the caller promises not to change while it uses `model_id` (!= 0; a fresh id after
+   every init): the Gaussian / Wendland sweep's per-model preprocessing -- Morton cell sort of the centres, packed
+   {x, w} records, tile boxes -- is then done once per (model_id, d_x, d_w, n, dim, kind) and reused by later calls
+   on this context (the single-point call behind gsl_sinterp_eval_e pays 1 launch instead of 9).  model_id = 0 is
+   gsl_sinterp_hip_rbf_eval: nothing is assumed about the buffers, nothing cached.  Same bits either way. */
+int gsl_sinterp_hip_rbf_eval_model(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x,
+                                   size_t n, int dim, size_t xtda, const double *d_w,
+                                   const double *d_y, size_t m, size_t ytda, double *d_s, unsigned long long model_id);
 
 /* "init" of an RBF interpolant in one call: fill d_phi (n x n scratch, lda), solve Phi w = f
    with d_w holding f on entry and w on exit.  *h_route reports the solver used:

@@ -98,6 +98,55 @@ def test_c4_full_size_gaussian_10m_targets(pkg, orc):
     assert relerr(d_c.cpu().numpy(), f) < 1e-9
 
 
+def test_c3_full_size_gaussian_3d_1m_targets(pkg, orc):
+    """C3 at its own size: N = 16384 3-D Gaussian, M = 10^6 resident targets through the 3-D cell sort and the
+    culled sweep (rbf_eval_gauss_cull_kernel<0,3,1>).  The oracle's gaxpy Cholesky at N = 16384 is ~25 min of one
+    core, so the WEIGHTS are pinned by the residual of the oracle's naive sums (libm exp, j ascending) of rows of
+    Phi w - f on 2048 sampled rows, the VALUES by the oracle's naive sweep on >= 10^4 targets spread over the whole
+    index range (<= 1e-10), plus run-to-run bit equality and far targets exactly 0."""
+    n, dim, m = 16384, 3, 1_000_000
+    eps = orc.gaussian_eps(n, dim)
+    x = orc.synth_centres(n, dim)
+    f = orc.synth_response(x)
+    ctx = pkg.HipContext.on_torch_stream(0)
+    f64 = torch.float64
+    d_x = dev(x)
+    d_w = dev(f)
+    d_phi = torch.empty((n, n), dtype=f64, device="cuda")
+    st, route = ctx.rbf_solve(0, eps, ptr(d_x), n, dim, dim, ptr(d_phi), n, ptr(d_w))
+    assert st == 0 and route == 1
+    ctx.sync()
+    del d_phi
+    w = d_w.cpu().numpy()
+    rows = np.arange(0, n, 8)
+    phiw = orc.rbf_eval(0, eps, x, w, np.ascontiguousarray(x[rows]))     # (Phi w)_i by the oracle, 3.4e7 pair evaluations
+    res = np.abs(phiw - f[rows]).max() / np.abs(f).max()
+    print(f"C3 weights: residual on {len(rows)} sampled rows {res:.3e}")
+    assert res < 1e-12
+    d_y = torch.empty((m, dim), dtype=f64, device="cuda")
+    ctx.synth_unit(0xC0FFEE02, 0, 0.02, 0.96, ptr(d_y), m * dim)
+    d_y[-1000:] += 50.0
+    d_s = torch.full((m,), 7.0, dtype=f64, device="cuda")
+    ctx.rbf_eval(0, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), m, dim, ptr(d_s))
+    ctx.sync()
+    assert bool(torch.isfinite(d_s).all())
+    assert bool((d_s[-1000:] == 0.0).all())                # every term below the cut-off -> exactly 0
+    idx = np.concatenate([np.arange(0, m - 1000, 97), np.arange(m - 1000, m, 100)])
+    yh = d_y[torch.from_numpy(idx).cuda()].cpu().numpy()
+    want = orc.rbf_eval(0, eps, x, w, np.ascontiguousarray(yh))       # 1.7e8 pair evaluations, ~4 s
+    got = d_s.cpu().numpy()[idx]
+    print(f"C3 values on {len(idx)} sampled targets: rel err {relerr(got, want):.3e}")
+    assert relerr(got, want) < TOL
+    d_s2 = torch.empty(m, dtype=f64, device="cuda")
+    ctx.rbf_eval(0, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), m, dim, ptr(d_s2))
+    ctx.sync()
+    assert bool(torch.equal(d_s, d_s2))                    # run to run bit-identical
+    d_c = torch.empty(n, dtype=f64, device="cuda")
+    ctx.rbf_eval(0, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_x), n, dim, ptr(d_c))
+    ctx.sync()
+    assert relerr(d_c.cpu().numpy(), f) < 1e-9
+
+
 def test_c5_full_size_bary_10m_targets(pkg, orc):
     n, m = 50_000, 10_000_000
     x = orc.synth_centres(n, 2)

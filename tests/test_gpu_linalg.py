@@ -180,9 +180,11 @@ def test_gemm_stream_k_is_reproducible(pkg):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [16640, 4100])
-def test_single_launch_sweeps_more_blocks_than_cus(pkg, n):
-    """The dataflow sweep kernel gives one 64-row block to each workgroup; with n = 16640 there are
-    260 blocks for 256 CUs, so some workgroups own two.  Property check at full size (no oracle run):
+def test_single_launch_sweeps_grid_stride_beyond_the_cu_count(pkg, n):
+    """The dataflow sweep kernel is launched with min(blocks, #CUs) workgroups -- one per CU, so every workgroup
+    of the launch is co-resident BY CONSTRUCTION (the launch never exceeds CUs x resident workgroups; that is the
+    guarantee the spin-waits rest on) -- and takes the 64-row blocks in grid-stride order: with n = 16640 there are
+    260 blocks for 256 workgroups, so four workgroups own two.  Property check at full size (no oracle run):
     (L L^T) x = b with a synthetic well-conditioned factor, residual computed with torch on the GPU."""
     g = torch.Generator(device="cuda").manual_seed(n)
     L = torch.rand((n, n), dtype=torch.float64, device="cuda", generator=g)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import dev, ptr
+from gpu_util import bits, dev, ptr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -321,3 +321,56 @@ def test_wendland_checkpoint_round_trip(pkg, orc, tmp_path):
     assert st == 0 and np.array_equal(va, vb)
     c = pkg.Sinterp("gaussian", dim, n, 0)                           # a checkpoint of another kernel is refused
     assert c.fread(path) != 0
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_clustered_centres_with_outlier_are_bit_reproducible(pkg, orc, dim):
+    """a far outlier stretches the bounding box of the centre sort, so thousands of centres share one
+    Morton cell.  The sweep must still sum every cell in ORIGINAL index order (cell_rank_kernel ranks a cell of any
+    size): two runs, two contexts (each sorts its own centres, like the members of a device group) and a shuffled
+    target batch all give the same bits, and the values match the oracle's naive sums."""
+    n, m = 6000, 20000
+    rng = np.random.default_rng(77 + dim)
+    x = 0.5 + 0.01 * rng.random((n, dim))                  # one tight cluster ...
+    x[-1] = 400.0                                          # ... and one outlier: > 4000 centres per cell
+    w = rng.standard_normal(n)
+    y = 0.5 + 0.01 * rng.random((m, dim))
+    eps = 2.0 * (n ** (1.0 / dim)) / 0.01 * 0.25           # a few hundred centres inside the cut-off radius
+    d_x, d_w, d_y = dev(x), dev(w), dev(y)
+    outs = []
+    for ctx in (pkg.HipContext.on_torch_stream(0), pkg.HipContext.on_torch_stream(0)):
+        for rep in range(2):
+            d_s = torch.empty(m, dtype=torch.float64, device="cuda")
+            ctx.rbf_eval(0, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), m, dim, ptr(d_s))
+            ctx.sync()
+            outs.append(d_s.cpu().numpy())
+    for o in outs[1:]:
+        assert np.array_equal(bits(outs[0]), bits(o))
+    want = orc.rbf_eval(0, eps, x, w, y)
+    assert relerr(outs[0], want) < TOL
+
+
+def test_model_cached_sweep_equals_uncached(pkg, orc):
+    """gsl_sinterp_hip_rbf_eval_model: with a model id the packed centres are kept between calls; the values are
+    the bits of the uncached sweep, a new id (or new pointers) repacks, id 0 never caches."""
+    n, dim, m = 5000, 2, 30000
+    x = orc.synth_centres(n, dim)
+    eps = orc.gaussian_eps(n, dim)
+    rng = np.random.default_rng(5)
+    w1, w2 = rng.standard_normal(n), rng.standard_normal(n)
+    y = orc.synth_targets(0, m, dim)
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_x, d_w, d_y = dev(x), dev(w1), dev(y)
+
+    def sweep(mid, mm=m):
+        d_s = torch.empty(mm, dtype=torch.float64, device="cuda")
+        ctx.rbf_eval(0, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), mm, dim, ptr(d_s), model_id=mid)
+        ctx.sync()
+        return d_s.cpu().numpy()
+    base = sweep(0)
+    assert np.array_equal(bits(base), bits(sweep(11))) and np.array_equal(bits(base), bits(sweep(11)))
+    assert np.array_equal(bits(base[:1]), bits(sweep(11, 1)))            # the single-point call reuses the cache
+    d_w.copy_(dev(w2))                                                   # same pointers, new content -> new id
+    want2 = orc.rbf_eval(0, eps, x, w2, y)
+    assert relerr(sweep(12), want2) < TOL
+    assert relerr(sweep(0), want2) < TOL

@@ -89,3 +89,44 @@ def test_tree_checkpoint_round_trip(pkg, orc, tmp_path):
     corrupt[off:off + 4] = (2 ** 30).to_bytes(4, "little")
     (tmp_path / "corrupt.bin").write_bytes(bytes(corrupt))
     assert pkg.SimplexTree.fread(tmp_path / "corrupt.bin") is None
+
+
+def test_tree_checkpoint_rejects_corrupt_headers_and_links(pkg, orc, tmp_path):
+    """simplex_tree_fread bounds the header counts (no multi-GB allocation / int overflow from 8 corrupt
+    bytes), requires the shuffle to be a permutation and child links to point forward (acyclic DAG)."""
+    import struct
+    n = 40
+    x = orc.synth_centres(n, 2)
+    t = pkg.SimplexTree(2, n)
+    assert t.init(x, flags=0, rng=pkg.capi.Rng(0)) == 0
+    good = tmp_path / "tree.bin"
+    assert t.fwrite(str(good)) == 0
+    raw = bytearray(good.read_bytes())
+    head = list(struct.unpack_from("<6i", raw, 8))                       # version, dim, n_nodes, n_points, max_points, 0
+    nn = head[2]
+
+    def load(buf):
+        p = tmp_path / "bad.bin"
+        p.write_bytes(bytes(buf))
+        try:
+            return pkg.SimplexTree.fread(str(p))
+        except pkg.capi.GslError:
+            return None
+    assert load(raw) is not None
+    for field, value in ((2, 2**31 - 1), (4, 2**31 - 1), (4, 2**31 // 9 + 5), (2, 9 * head[4] + 9)):
+        bad = bytearray(raw)
+        h = list(head); h[field] = value
+        struct.pack_into("<6i", bad, 8, *h)
+        assert load(bad) is None
+    # shuffle with a repeated entry: last 8 bytes := first shuffle entry
+    off_shuffle = len(raw) - 8 * head[4]
+    bad = bytearray(raw)
+    bad[-8:] = bad[off_shuffle:off_shuffle + 8]
+    assert load(bad) is None
+    # an inner node whose first child link points back at the root: a cycle for find_leaf
+    off_links = 8 + 24 + 4 * nn + 12 * nn
+    types = struct.unpack_from(f"<{nn}i", raw, 32)
+    inner = next(k for k in range(1, nn) if types[k] != 0)
+    bad = bytearray(raw)
+    struct.pack_into("<i", bad, off_links + 12 * inner, 0)
+    assert load(bad) is None
