@@ -13,5 +13,5 @@ The directory name contains a hyphen, so load it through
 from . import capi, sharding  # noqa: F401
 from .capi import (  # noqa: F401
     GSL_SUCCESS, GSL_EDOM, GSL_EINVAL, GSL_EFAILED, RBF_GAUSSIAN, RBF_TPS, RBF_WENDLAND,
-    HipContext, SimplexTree, Sinterp, lib, library_path,
+    HipContext, SimplexMesh, SimplexTree, Sinterp, lib, library_path,
 )

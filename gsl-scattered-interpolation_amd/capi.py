@@ -92,7 +92,7 @@ class gsl_sinterp(C.Structure):
     _fields_ = [("type", C.c_void_p), ("dim", C.c_size_t), ("size", C.c_size_t), ("device", C.c_int),
                 ("shape", C.c_double), ("init_flags", C.c_int), ("rng", C.c_void_p), ("state", C.c_void_p),
                 ("n_devices", C.c_int), ("devices", C.c_int * 64), ("solver", C.c_int), ("want_rcond", C.c_int),
-                ("rcond", C.c_double), ("route", C.c_int)]
+                ("rcond", C.c_double), ("route", C.c_int), ("nugget", C.c_double)]
 
 
 _vp, _i, _sz, _d = C.c_void_p, C.c_int, C.c_size_t, C.c_double
@@ -187,11 +187,34 @@ SIGNATURES = {
     "simplex_tree_device_alloc_multi": (_vp, [_pt, _pm, _pi, _i]),
     "simplex_tree_device_n_devices": (_i, [_vp]),
     "simplex_tree_device_transport": (C.c_char_p, [_vp]),
+    # --- part 2b: imported triangulations
+    "simplex_mesh_import": (_vp, [_pm, _pi, _pi, _sz]),
+    "simplex_mesh_from_tree": (_vp, [_pt, _pm]),
+    "simplex_mesh_free": (None, [_vp]),
+    "simplex_mesh_n_triangles": (_sz, [_vp]),
+    "simplex_mesh_n_points": (_sz, [_vp]),
+    "simplex_mesh_triangles": (_pi, [_vp]),
+    "simplex_mesh_neighbours": (_pi, [_vp]),
+    "simplex_mesh_tree_nodes": (_pi, [_vp]),
+    "simplex_mesh_geometry": (None, [_vp, _pd, _pd]),
+    "simplex_mesh_set_convex": (None, [_vp, _i]),
+    "simplex_mesh_device_alloc": (_vp, [_vp, _i]),
+    "simplex_mesh_device_free": (None, [_vp]),
+    "simplex_mesh_device_set_response": (_i, [_vp, _pv]),
+    "simplex_mesh_device_eval_many": (_i, [_vp, _pm, _pv, _pi]),
+    "simplex_mesh_device_eval_resident": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "simplex_mesh_device_ctx": (_vp, [_vp]),
+    "gsl_sinterp_hip_mesh_pack": (_i, [_vp, _i, _vp, _vp, _i, _vp, _pd, _i, _vp, _vp]),
+    "gsl_sinterp_hip_mesh_eval": (_i, [_vp, _i, _vp, _vp, _vp, _i, _pd, _i, _vp, _sz, _sz, _vp, _vp, C.POINTER(C.c_longlong)]),
     # --- part 3
     "gsl_sinterp_alloc": (C.POINTER(gsl_sinterp), [_vp, _sz, _sz]),
     "gsl_sinterp_set_device": (_i, [C.POINTER(gsl_sinterp), _i]),
     "gsl_sinterp_set_shape": (_i, [C.POINTER(gsl_sinterp), _d]),
     "gsl_sinterp_set_solver": (_i, [C.POINTER(gsl_sinterp), _i]),
+    "gsl_sinterp_set_nugget": (_i, [C.POINTER(gsl_sinterp), _d]),
+    "gsl_sinterp_mean": (_i, [C.POINTER(gsl_sinterp), _pd]),
+    "gsl_sinterp_hip_krige_solve": (_i, [_vp, _i, _d, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _pd, _pi]),
+    "gsl_sinterp_hip_krige_eval": (_i, [_vp, _i, _d, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp, C.c_uint64]),
     "gsl_sinterp_set_rcond": (_i, [C.POINTER(gsl_sinterp), _i]),
     "gsl_sinterp_rcond": (_i, [C.POINTER(gsl_sinterp), _pd]),
     "gsl_sinterp_route": (_i, [C.POINTER(gsl_sinterp)]),
@@ -220,7 +243,7 @@ SIGNATURES = {
     "gsl_rng_get": (C.c_ulong, [_vp]),
     "gsl_rng_uniform_int": (C.c_ulong, [_vp, C.c_ulong]),
 }
-DATA_SYMBOLS = ["gsl_sinterp_rbf_gaussian", "gsl_sinterp_rbf_tps", "gsl_sinterp_rbf_wendland", "gsl_sinterp_linear_simplex",
+DATA_SYMBOLS = ["gsl_sinterp_kriging", "gsl_sinterp_rbf_gaussian", "gsl_sinterp_rbf_tps", "gsl_sinterp_rbf_wendland", "gsl_sinterp_linear_simplex",
                 "gsl_rng_mt19937", "gsl_rng_default"]
 
 
@@ -622,10 +645,112 @@ class DeviceTree:
             pass
 
 
+class SimplexMesh:
+    """An imported triangulation (QHull / CGAL style arrays) or the final triangulation of a SimplexTree."""
+
+    def __init__(self, handle, keep=None):
+        if not handle:
+            raise GslError(GSL_EINVAL, "simplex_mesh")
+        self._h = C.c_void_p(handle)
+        self._keep = keep
+
+    @classmethod
+    def from_arrays(cls, points, triangles, neighbours=None):
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        tri = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        nbr = None if neighbours is None else np.ascontiguousarray(neighbours, dtype=np.int32).reshape(-1, 3)
+        h = lib().simplex_mesh_import(C.byref(as_matrix(pts)), tri.ctypes.data_as(_pi),
+                                      nbr.ctypes.data_as(_pi) if nbr is not None else None, len(tri))
+        return cls(h)
+
+    @classmethod
+    def from_tree(cls, tree):
+        return cls(lib().simplex_mesh_from_tree(tree._t, tree._m()), keep=tree)
+
+    @property
+    def n_triangles(self):
+        return int(lib().simplex_mesh_n_triangles(self._h))
+
+    def _ints(self, fn, width):
+        p = fn(self._h)
+        if not p:
+            return None
+        n = self.n_triangles
+        return np.ctypeslib.as_array(p, shape=(n * width,)).reshape(n, width).copy() if width > 1 else \
+            np.ctypeslib.as_array(p, shape=(n,)).copy()
+
+    def triangles(self):
+        return self._ints(lib().simplex_mesh_triangles, 3)
+
+    def neighbours(self):
+        return self._ints(lib().simplex_mesh_neighbours, 3)
+
+    def tree_nodes(self):
+        return self._ints(lib().simplex_mesh_tree_nodes, 1)
+
+    def geometry(self):
+        sh, sc = (C.c_double * 2)(), (C.c_double * 2)()
+        lib().simplex_mesh_geometry(self._h, sh, sc)
+        return np.array(sh[:]), np.array(sc[:])
+
+    def set_convex(self, convex):
+        lib().simplex_mesh_set_convex(self._h, int(convex))
+
+    def device_alloc(self, device=0):
+        h = lib().simplex_mesh_device_alloc(self._h, device)
+        if not h:
+            raise GslError(GSL_EFAILED, "simplex_mesh_device_alloc")
+        return DeviceMesh(h, self)
+
+    def close(self):
+        if self._h:
+            lib().simplex_mesh_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceMesh:
+    def __init__(self, handle, mesh):
+        self._h = C.c_void_p(handle)
+        self._mesh = mesh
+
+    def set_response(self, response):
+        return lib().simplex_mesh_device_set_response(self._h, C.byref(as_vector(response)))
+
+    def eval_many(self, targets):
+        m = targets.shape[0]
+        vals = np.empty(m, dtype=np.float64)
+        tri = np.empty(m, dtype=np.int32)
+        st = lib().simplex_mesh_device_eval_many(self._h, C.byref(as_matrix(targets)), C.byref(as_vector(vals)), tri.ctypes.data_as(_pi))
+        return st, vals, tri
+
+    def eval_resident(self, d_targets, m, ttda, d_values, d_tri):
+        return lib().simplex_mesh_device_eval_resident(self._h, d_targets, m, ttda, d_values, d_tri)
+
+    def ctx_handle(self):
+        return lib().simplex_mesh_device_ctx(self._h)
+
+    def close(self):
+        if self._h:
+            lib().simplex_mesh_device_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------ facade
 class Sinterp:
     TYPES = {"gaussian": "gsl_sinterp_rbf_gaussian", "tps": "gsl_sinterp_rbf_tps", "wendland": "gsl_sinterp_rbf_wendland",
-             "linear_simplex": "gsl_sinterp_linear_simplex"}
+             "linear_simplex": "gsl_sinterp_linear_simplex", "kriging": "gsl_sinterp_kriging"}
 
     def __init__(self, kind, dim, size, device=0):
         self._p = lib().gsl_sinterp_alloc(_ptr(self.TYPES[kind]), dim, size)
@@ -636,6 +761,14 @@ class Sinterp:
 
     def set_shape(self, eps):
         return lib().gsl_sinterp_set_shape(self._p, eps)
+
+    def set_nugget(self, nugget):
+        return lib().gsl_sinterp_set_nugget(self._p, nugget)
+
+    def mean(self):
+        v = C.c_double(0)
+        st = lib().gsl_sinterp_mean(self._p, C.byref(v))
+        return st, v.value
 
     def set_solver(self, solver):
         return lib().gsl_sinterp_set_solver(self._p, solver)

@@ -78,7 +78,7 @@ __global__ void tree_pack_kernel(int n_nodes, const int *__restrict__ type, cons
   if (m00 != 0.0) { l10 = m10 / m00; u11 = m11 - l10 * m01; }
   int singular = (m00 == 0) || (u11 == 0);           /* linear_simplex_util.h:14-26 */
 
-  const int t = type[k];
+  const int t = type ? type[k] : 0;                   /* no type array: every node is a leaf (imported triangulation) */
   const int nchild = t == 1 ? 3 : (t == 0 ? 0 : 2);   /* linear_simplex.h:67-80 */
   NodeRec r;
   r.x0 = v[2][0]; r.x1 = v[2][1];
@@ -1001,6 +1001,237 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
     *h_n_outside = (long long)cnt;
     if (cnt) return sinterp_fail(ctx, ST_EDOM, "bary_eval: target(s) outside the caging simplex", hipSuccess, __FILE__, __LINE__);
+  }
+  return ST_SUCCESS;
+}
+
+
+/* ======================================================================== */
+/* Imported triangulations (the reference's README:28-31 lists "import triangulations
+   from QHull / CGAL" as future work).  Such a triangulation has no history DAG: only triangles and their edge
+   neighbours.  Located by SEED + WALK OVER THE LEAF ADJACENCY (interpolation/linear_simplex.h:62-63: link i of a leaf =
+   neighbour opposite vertex i):
+     * records: the same 64-byte NodeRec as a DAG leaf (tree_pack_kernel with no type array), child[] = neighbours,
+       -1 = hull edge; the same 32-byte response table (tree_bind_kernel);
+     * seed: a G x G grid over the points' bounding box, cell -> a triangle whose centroid lies in it (largest index:
+       atomicMax, deterministic), empty cells take the nearest filled cell of the surrounding rings;
+     * walk: barycentric coordinates of the target in the current triangle by the reference's arithmetic
+       (solve_node = calculate_bary_coords, linear_simplex.c:607-651); the closed containment rule of contains_point
+       (:653-676) ends the walk, otherwise it crosses the edge opposite the most negative coordinate.  The walk is
+       a function of (mesh, target) only -- the seed depends on the target alone -- so results do not depend on the
+       batch or the shard.  A target ON an edge or vertex belongs to every triangle that contains it; the walk
+       returns the first it reaches (with no reference walk to agree with, any containing triangle is the
+       reference's answer under its tie rule; the interpolated value is the same to rounding).
+     * hull edge in the crossing direction: outside -> index -1, value NaN (convex meshes: Delaunay output of QHull /
+       CGAL).  For a mesh declared non-convex, and for a walk that does not terminate within its bound (possible in
+       non-Delaunay input), the target goes to an exhaustive scan of all triangles (smallest containing index).
+   Values: interp_point's arithmetic (:678-711) in the located triangle, so a mesh exported from a simplex_tree
+   (same vertex order, same standardisation) returns the bits of the DAG path wherever the containing leaf is unique. */
+__global__ void mesh_seed_init_kernel(int *__restrict__ seed, size_t cells)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < cells) seed[c] = -1;
+}
+
+struct MeshGrid { double lo0, lo1, w0, w1; int G; };
+
+__device__ __forceinline__ int mesh_cell(const MeshGrid &g, double y0, double y1)
+{
+  int ix = (y0 == y0 && g.w0 > 0.0) ? (int)fmin(fmax((y0 - g.lo0) / g.w0, 0.0), (double)(g.G - 1)) : 0;
+  int iy = (y1 == y1 && g.w1 > 0.0) ? (int)fmin(fmax((y1 - g.lo1) / g.w1, 0.0), (double)(g.G - 1)) : 0;
+  return iy * g.G + ix;
+}
+
+__global__ void mesh_seed_kernel(int n_tri, const int *__restrict__ tri, int n_points, const double *__restrict__ points, MeshGrid g,
+                                 int *__restrict__ seed)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tri) return;
+  double c0 = 0.0, c1 = 0.0;
+  for (int i = 0; i < 3; i++) {
+    const int v = tri[3 * t + i];
+    if (v < 0 || v >= n_points) return;
+    c0 += points[2 * v]; c1 += points[2 * v + 1];
+  }
+  atomicMax(&seed[mesh_cell(g, c0 / 3.0, c1 / 3.0)], t);
+}
+
+#define MESH_SEED_RINGS 8
+__global__ void mesh_seed_fill_kernel(const int *__restrict__ seed_in, int *__restrict__ seed_out, int G)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= G * G) return;
+  int s = seed_in[c];
+  const int cx = c % G, cy = c / G;
+  for (int r = 1; r <= MESH_SEED_RINGS && s < 0; r++)          /* fixed scan order: deterministic */
+    for (int dy = -r; dy <= r && s < 0; dy++)
+      for (int dx = -r; dx <= r && s < 0; dx++) {
+        if (abs(dx) != r && abs(dy) != r) continue;
+        const int x = cx + dx, y = cy + dy;
+        if (x < 0 || y < 0 || x >= G || y >= G) continue;
+        s = seed_in[y * G + x];
+      }
+  seed_out[c] = s < 0 ? 0 : s;                                 /* nothing nearby: start at triangle 0 */
+}
+
+__device__ __forceinline__ void mesh_finish(const NodeRec &cur, const LeafRec *__restrict__ tab, int t, double y0, double y1, double s0,
+                                            double s1, size_t k, double *__restrict__ values, int *__restrict__ tri_out)
+{
+  double c0, c1;
+  solve_node(cur, y0, y1, s0, s1, c0, c1);
+  const LeafRec lr = tab[t];
+  double tot = 0, interp = 0;                                  /* linear_simplex.c:678-711 */
+  tot += c0;
+  if (lr.mask & 1) interp += c0 * lr.f[0];
+  tot += c1;
+  if (lr.mask & 2) interp += c1 * lr.f[1];
+  if (lr.mask & 4) interp += (1 - tot) * lr.f[2];
+  values[k] = interp;
+  if (tri_out) tri_out[k] = t;
+}
+
+/* todo: [0] = count, [1..] = indices of the targets left to the exhaustive scan */
+__global__ void __launch_bounds__(256)
+mesh_walk_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, const int *__restrict__ seed, MeshGrid g,
+                 double s0, double s1, int convex, int max_steps, const double *__restrict__ targets, size_t m, size_t ttda,
+                 double *__restrict__ values, int *__restrict__ tri_out, unsigned long long *__restrict__ n_outside,
+                 unsigned *__restrict__ todo)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
+  int t = seed[mesh_cell(g, y0, y1)];
+  int found = -2;                                              /* -2 walking, -1 outside, -3 exhaustive scan */
+  if (!(y0 == y0 && y1 == y1)) found = -1;                     /* NaN target: outside, like the DAG path */
+  NodeRec cur;
+  for (int step = 0; found == -2; step++) {
+    if (step >= max_steps || t < 0 || t >= n_tri) { found = -3; break; }
+    cur = load_rec(rec, t);
+    double c0, c1;
+    solve_node(cur, y0, y1, s0, s1, c0, c1);
+    if (inside_unit(c0, c1)) { found = t; break; }
+    const double c2 = 1.0 - (c0 + c1);
+    if (!(c0 == c0 && c1 == c1 && c2 == c2) || META_SINGULAR(cur.meta)) { found = -3; break; }   /* degenerate triangle */
+    /* the edge to cross: opposite the most negative coordinate; a hull edge there -> the next most negative one */
+    double v[3] = {c0, c1, c2};
+    int order[3] = {0, 1, 2};
+    if (v[order[1]] < v[order[0]]) { const int q = order[0]; order[0] = order[1]; order[1] = q; }
+    if (v[order[2]] < v[order[1]]) { const int q = order[1]; order[1] = order[2]; order[2] = q; }
+    if (v[order[1]] < v[order[0]]) { const int q = order[0]; order[0] = order[1]; order[1] = q; }
+    int next = -1;
+    for (int a = 0; a < 3 && next < 0; a++)
+      if (v[order[a]] < 0.0 && cur.child[order[a]] >= 0) next = cur.child[order[a]];
+    if (next < 0) { found = (v[order[0]] < 0.0 && convex) ? -1 : -3; break; }      /* only hull edges in the way */
+    t = next;
+  }
+  if (found >= 0) { mesh_finish(cur, tab, found, y0, y1, s0, s1, k, values, tri_out); return; }
+  if (found == -3) {
+    const unsigned slot = atomicAdd(&todo[0], 1u);
+    todo[1 + slot] = (unsigned)k;
+    return;
+  }
+  values[k] = __longlong_as_double(0x7ff8000000000000LL);
+  if (tri_out) tri_out[k] = -1;
+  atomicAdd(n_outside, 1ULL);
+}
+
+/* exhaustive scan: one workgroup per queued target, smallest index of a containing triangle */
+__global__ void __launch_bounds__(256)
+mesh_scan_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, double s0, double s1,
+                 const double *__restrict__ targets, size_t ttda, double *__restrict__ values, int *__restrict__ tri_out,
+                 unsigned long long *__restrict__ n_outside, const unsigned *__restrict__ todo)
+{
+  __shared__ int s_best;
+  const unsigned count = todo[0];
+  for (unsigned q = blockIdx.x; q < count; q += gridDim.x) {
+    const size_t k = todo[1 + q];
+    const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
+    if (threadIdx.x == 0) s_best = 0x7fffffff;
+    __syncthreads();
+    int best = 0x7fffffff;
+    for (int t = threadIdx.x; t < n_tri && t < best; t += blockDim.x) {
+      const NodeRec r = load_rec(rec, t);
+      double c0, c1;
+      solve_node(r, y0, y1, s0, s1, c0, c1);
+      if (!META_SINGULAR(r.meta) && inside_unit(c0, c1)) best = t;
+    }
+    if (best != 0x7fffffff) atomicMin(&s_best, best);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = s_best;
+      if (t != 0x7fffffff) mesh_finish(load_rec(rec, t), tab, t, y0, y1, s0, s1, k, values, tri_out);
+      else {
+        values[k] = __longlong_as_double(0x7ff8000000000000LL);
+        if (tri_out) tri_out[k] = -1;
+        atomicAdd(n_outside, 1ULL);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+/* h_geom[8] = shift(2), scale(2), bounding box of the points lo0, lo1, hi0, hi1; d_seed: 2 G^2 ints */
+extern "C" int gsl_sinterp_hip_mesh_pack(gsl_sinterp_hip_ctx *ctx, int n_tri, const int *d_tri, const int *d_nbr, int n_points,
+                                         const double *d_points, const double *h_geom, int G, void *d_records, int *d_seed)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  REQUIRE(ctx, n_tri > 0 && n_points >= 3 && G >= 1 && G <= 4096, ST_EINVAL);
+  REQUIRE(ctx, d_tri && d_nbr && d_points && h_geom && d_records && d_seed, ST_EFAULT);
+  REQUIRE(ctx, ((uintptr_t)d_records & 63) == 0, ST_EINVAL);
+  Geom g;
+  for (int i = 0; i < 6; i++) g.seed[i] = 0.0;
+  g.shift[0] = h_geom[0]; g.shift[1] = h_geom[1];
+  g.scale[0] = h_geom[2]; g.scale[1] = h_geom[3];
+  hipLaunchKernelGGL(tree_pack_kernel, dim3((n_tri + 255) / 256), dim3(256), 0, ctx->stream, n_tri, (const int *)NULL, d_tri, d_nbr,
+                     n_points, d_points, g, (NodeRec *)d_records);
+  MeshGrid mg;
+  mg.lo0 = h_geom[4]; mg.lo1 = h_geom[5]; mg.w0 = (h_geom[6] - h_geom[4]) / G; mg.w1 = (h_geom[7] - h_geom[5]) / G; mg.G = G;
+  const size_t cells = (size_t)G * G;
+  hipLaunchKernelGGL(mesh_seed_init_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, d_seed + cells, cells);
+  hipLaunchKernelGGL(mesh_seed_kernel, dim3((n_tri + 255) / 256), dim3(256), 0, ctx->stream, n_tri, d_tri, n_points, d_points, mg,
+                     d_seed + cells);
+  hipLaunchKernelGGL(mesh_seed_fill_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const int *)(d_seed + cells), d_seed, G);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_mesh_eval(gsl_sinterp_hip_ctx *ctx, int n_tri, const void *d_records, const void *d_leaftab,
+                                         const int *d_seed, int G, const double *h_geom, int convex, const double *d_targets,
+                                         size_t m, size_t ttda, double *d_values, int *d_tri, long long *h_n_outside)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  REQUIRE(ctx, n_tri > 0 && ttda >= 2 && G >= 1, ST_EINVAL);
+  REQUIRE(ctx, d_records && d_leaftab && d_seed && h_geom && (m == 0 || (d_targets && d_values)), ST_EFAULT);
+  if (h_n_outside) *h_n_outside = 0;
+  if (m == 0) return ST_SUCCESS;
+  REQUIRE(ctx, m < 0xffffffffULL, ST_EINVAL);
+  unsigned long long *d_count = (unsigned long long *)ctx->d_scratch;
+  HIP_OK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+  void *buf = NULL;
+  int st = sinterp_walkbuf(ctx, (m + 1) * sizeof(unsigned), &buf);      /* queue of the exhaustive scan */
+  if (st) return st;
+  unsigned *todo = (unsigned *)buf;
+  HIP_OK(ctx, hipMemsetAsync(todo, 0, sizeof(unsigned), ctx->stream));
+  MeshGrid mg;
+  mg.lo0 = h_geom[4]; mg.lo1 = h_geom[5]; mg.w0 = (h_geom[6] - h_geom[4]) / G; mg.w1 = (h_geom[7] - h_geom[5]) / G; mg.G = G;
+  /* a straight walk from a grid seed crosses a handful of triangles; the bound only guards against cycles */
+  const int max_steps = 64 + 4 * G;
+  hipLaunchKernelGGL(mesh_walk_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, n_tri, (const NodeRec *)d_records,
+                     (const LeafRec *)d_leaftab, d_seed, mg, h_geom[2], h_geom[3], convex, max_steps, d_targets, m, ttda, d_values,
+                     d_tri, d_count, todo);
+  hipLaunchKernelGGL(mesh_scan_kernel, dim3(256), dim3(256), 0, ctx->stream, n_tri, (const NodeRec *)d_records,
+                     (const LeafRec *)d_leaftab, h_geom[2], h_geom[3], d_targets, ttda, d_values, d_tri, d_count,
+                     (const unsigned *)todo);
+  LAUNCH_CHECK(ctx);
+  if (h_n_outside) {
+    unsigned long long c = 0;
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_OK(ctx, hipMemcpy(&c, d_count, sizeof c, hipMemcpyDeviceToHost));
+    *h_n_outside = (long long)c;
+    if (c) { snprintf(ctx->err, sizeof ctx->err, "mesh_eval: %llu target(s) outside the triangulation", c); return ST_EDOM; }
   }
   return ST_SUCCESS;
 }

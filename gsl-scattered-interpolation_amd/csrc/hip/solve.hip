@@ -309,3 +309,107 @@ extern "C" int gsl_sinterp_hip_rbf_solve_ex(gsl_sinterp_hip_ctx *ctx, int kind, 
   if (!st && h_route) *h_route = 6;
   return st;
 }
+
+
+/* ------------------------------------------------------------------------ */
+/* Ordinary kriging (the reference's README:24 lists kriging as future work): the dual form on the covariance
+   C(h) = phi(h) with a nugget,
+       [K 1; 1^T 0] [w; mu] = [f; 0],  K = Phi + nugget I,      s(y) = mu + sum_j w_j phi(|y - x_j|),
+   solved as  a = K^-1 f, b = K^-1 1, mu = (1^T a) / (1^T b), w = a - mu b : ONE factorisation, two right-hand sides
+   through the blocked sweeps.  K is SPD for a positive definite kernel (route 7: the MFMA Cholesky); a
+   semi-definite K (duplicate sites with nugget 0) fails there with GSL_EDOM and goes through the pivoted LDL^T
+   of linalg/pcholesky.c (route 8). */
+__global__ void __launch_bounds__(256)
+diag_add_kernel(double *__restrict__ a, size_t lda, size_t n, double v)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i * lda + i] += v;
+}
+
+__global__ void __launch_bounds__(256)
+krige_rhs_kernel(const double *__restrict__ f, size_t n, double *__restrict__ Y, double *__restrict__ ones)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { Y[i] = f[i]; Y[n + i] = 1.0; ones[i] = 1.0; }
+}
+
+__global__ void __launch_bounds__(256)
+add_const_kernel(double *__restrict__ s, size_t m, double c)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) s[k] = s[k] + c;
+}
+
+extern "C" int gsl_sinterp_hip_krige_solve(gsl_sinterp_hip_ctx *ctx, int kind, double eps, double nugget, const double *d_x, size_t n,
+                                           int dim, size_t xtda, double *d_phi, size_t lda, double *d_w, double *h_mean,
+                                           int *h_route)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  EXCLUSIVE_SECTION(ctx);
+  REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && lda >= n && nugget >= 0.0, ST_EINVAL);
+  REQUIRE(ctx, kind == GSL_SINTERP_RBF_GAUSSIAN || kind == GSL_SINTERP_RBF_WENDLAND, ST_EINVAL);   /* covariances: positive definite kernels */
+  REQUIRE(ctx, h_mean != NULL && (n == 0 || (d_x && d_phi && d_w)), ST_EFAULT);
+  if (h_route) *h_route = 0;
+  *h_mean = 0.0;
+  if (n == 0) return ST_SUCCESS;
+  void *aux = NULL;
+  int st = sinterp_aux(ctx, (3 * n + 64) * sizeof(double), &aux);
+  if (st) return st;
+  double *Y = (double *)aux, *ones = Y + 2 * n, *G = ones + n;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  int route = 7;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);       /* both triangles: the pivoted route needs them */
+    if (st) return st;
+    if (nugget != 0.0) hipLaunchKernelGGL(diag_add_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_phi, lda, n, nugget);
+    hipLaunchKernelGGL(krige_rhs_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_w, n, Y, ones);
+    LAUNCH_CHECK(ctx);
+    if (attempt == 0) {
+      int info = 0;
+      st = sinterp_cholesky_decomp1_sym(ctx, n, d_phi, lda, &info);
+      if (st == ST_EDOM) continue;                                                      /* only semi-definite: pivoted LDL^T */
+      if (st) return st;
+      st = sinterp_cholesky_svx_multi(ctx, n, d_phi, lda, Y, n, 2);
+      if (st) return st;
+      break;
+    }
+    route = 8;
+    int *d_perm = NULL;
+    st = gsl_sinterp_hip_malloc(ctx, (void **)&d_perm, n * sizeof(int));
+    if (!st) st = gsl_sinterp_hip_pcholesky_decomp(ctx, n, d_phi, lda, d_perm);
+    if (!st) st = gsl_sinterp_hip_pcholesky_svx(ctx, n, d_phi, lda, d_perm, Y);
+    if (!st) st = gsl_sinterp_hip_pcholesky_svx(ctx, n, d_phi, lda, d_perm, Y + n);
+    if (!st) st = gsl_sinterp_hip_sync(ctx);
+    gsl_sinterp_hip_free(ctx, d_perm);
+    if (st) return st;
+  }
+  hipLaunchKernelGGL(gram_kernel, dim3(2), dim3(256), 0, ctx->stream, (const double *)ones, (const double *)Y, n, 1, G);   /* 1^T a, 1^T b */
+  LAUNCH_CHECK(ctx);
+  double hG[2] = {0.0, 0.0};
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(hG, G, sizeof hG, hipMemcpyDeviceToHost));
+  if (!(hG[1] != 0.0) || hG[1] != hG[1])
+    return sinterp_fail(ctx, ST_EDOM, "krige_solve: 1^T K^-1 1 = 0 (degenerate covariance matrix)", hipSuccess, __FILE__, __LINE__);
+  const double mu = hG[0] / hG[1], coef = -mu;
+  HIP_OK(ctx, hipMemcpyAsync(G, &coef, sizeof coef, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(combine_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)Y, n, 1, (const double *)G, d_w);
+  LAUNCH_CHECK(ctx);
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));                                        /* coef is a stack variable */
+  *h_mean = mu;
+  if (h_route) *h_route = route;
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_krige_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, double mean, const double *d_x, size_t n,
+                                          int dim, size_t xtda, const double *d_w, const double *d_y, size_t m, size_t ytda,
+                                          double *d_s, unsigned long long model_id)
+{
+  int st = gsl_sinterp_hip_rbf_eval_model(ctx, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, model_id);
+  if (st || m == 0) return st;
+  size_t blocks = (m + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_const_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_s, m, mean);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}

@@ -527,6 +527,9 @@ typedef struct {
   /* id of the model the buffers hold (fresh after every init / fread): lets the sweep keep its per-model
      preprocessing between evaluations (gsl_sinterp_hip_rbf_eval_model) */
   unsigned long long model_id;
+  /* ordinary kriging (gsl_sinterp_kriging): the kernel is the covariance, `mean` the estimated mean added by every sweep */
+  int krige;
+  double mean;
 } rbf_state;
 
 static unsigned long long next_model_id(void)
@@ -545,6 +548,12 @@ static void *rbf_alloc_kind(int kind, size_t dim, size_t size)
 static void *rbf_gauss_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_GAUSSIAN, dim, size); }
 static void *rbf_tps_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_TPS, dim, size); }
 static void *rbf_wendland_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_WENDLAND, dim, size); }
+static void *krige_alloc(size_t dim, size_t size)
+{
+  rbf_state *st = (rbf_state *)rbf_alloc_kind(GSL_SINTERP_RBF_GAUSSIAN, dim, size);      /* Gaussian covariance */
+  if (st) st->krige = 1;
+  return st;
+}
 
 static void rbf_release_devices(rbf_state *st)
 {
@@ -601,8 +610,11 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
   /* fill + dense solve on the device: Cholesky (Gaussian), shifted-SPD Cholesky with a
      Woodbury correction or pivoted LU (thin-plate spline) -- csrc/hip/solve.hip */
   double rcond = GSL_NAN;
-  if (!s) s = gsl_sinterp_hip_rbf_solve_ex(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, interp->solver,
-                                           interp->want_rcond ? &rcond : NULL, &route);
+  if (!s && st->krige)
+    s = gsl_sinterp_hip_krige_solve(c, st->kind, st->eps, interp->nugget, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, &st->mean, &route);
+  else if (!s)
+    s = gsl_sinterp_hip_rbf_solve_ex(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, interp->solver,
+                                     interp->want_rcond ? &rcond : NULL, &route);
   interp->rcond = rcond; interp->route = route;
   /* replicate the solved model: ONE broadcast of the weight vector (+ centres) */
   if (!s && st->ss.grp) s = gsl_sinterp_hip_group_broadcast(st->ss.grp, (void *const *)st->m_model, model_bytes);
@@ -661,8 +673,13 @@ static int rbf_eval_resident(const gsl_sinterp *interp, const double *d_y, size_
   if (!st->d_w) GSL_ERROR("gsl_sinterp_eval: interpolant not initialised", GSL_EINVAL);
   /* resident buffers live on ONE device: member 0 evaluates them (shard resident targets yourself with
      gsl_sinterp_hip_shard_bounds + one interpolant per device, as bench.py does per process) */
-  HIP_TRY(gsl_sinterp_hip_rbf_eval_model(st->ctx, st->kind, st->eps, st->d_x, st->n, (int)st->dim, st->dim,
-                                         st->d_w, d_y, m, ytda, d_s, st->model_id), st->ctx);
+  if (!st->krige) {
+    HIP_TRY(gsl_sinterp_hip_rbf_eval_model(st->ctx, st->kind, st->eps, st->d_x, st->n, (int)st->dim, st->dim, st->d_w, d_y, m, ytda, d_s,
+                                           st->model_id), st->ctx);
+    return GSL_SUCCESS;
+  }
+  HIP_TRY(gsl_sinterp_hip_krige_eval(st->ctx, st->kind, st->eps, st->mean, st->d_x, st->n, (int)st->dim, st->dim,
+                                     st->d_w, d_y, m, ytda, d_s, st->model_id), st->ctx);
   return GSL_SUCCESS;
 }
 
@@ -671,6 +688,9 @@ static int rbf_shard_eval(void *state, int member, const double *d_y, size_t m, 
   (void)d_leaf;
   rbf_state *st = (rbf_state *)state;
   const double *model = st->m_model[member];
+  if (st->krige)
+    return gsl_sinterp_hip_krige_eval(gsl_sinterp_hip_group_ctx(st->ss.grp, member), st->kind, st->eps, st->mean, model, st->n,
+                                      (int)st->dim, st->dim, model + st->n * st->dim, d_y, m, st->dim, d_s, st->model_id);
   return gsl_sinterp_hip_rbf_eval_model(gsl_sinterp_hip_group_ctx(st->ss.grp, member), st->kind, st->eps, model, st->n, (int)st->dim,
                                         st->dim, model + st->n * st->dim, d_y, m, st->dim, d_s, st->model_id);
 }
@@ -698,7 +718,8 @@ static int rbf_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vec
   int s = gsl_sinterp_hip_malloc(c, (void **)&d_y, m * dim * sizeof(double));
   if (!s) s = gsl_sinterp_hip_malloc(c, (void **)&d_s, m * sizeof(double));
   if (!s) s = gsl_sinterp_hip_h2d(c, d_y, h_y, m * dim * sizeof(double));
-  if (!s) s = gsl_sinterp_hip_rbf_eval_model(c, st->kind, st->eps, st->d_x, st->n, (int)dim, dim, st->d_w, d_y, m, dim, d_s, st->model_id);
+  if (!s && st->krige) s = gsl_sinterp_hip_krige_eval(c, st->kind, st->eps, st->mean, st->d_x, st->n, (int)dim, dim, st->d_w, d_y, m, dim, d_s, st->model_id);
+  else if (!s) s = gsl_sinterp_hip_rbf_eval_model(c, st->kind, st->eps, st->d_x, st->n, (int)dim, dim, st->d_w, d_y, m, dim, d_s, st->model_id);
   if (!s) s = gsl_sinterp_hip_d2h(c, h_s, d_s, m * sizeof(double));
   if (!s) for (size_t k = 0; k < m; k++) gsl_vector_set(sv, k, h_s[k]);
   if (!s && leaf) for (size_t k = 0; k < m; k++) leaf[k] = -1;
@@ -793,6 +814,8 @@ static const gsl_sinterp_type gauss_type = {"rbf-gaussian", 1, &rbf_gauss_alloc,
 static const gsl_sinterp_type tps_type = {"rbf-thin-plate-spline", 1, &rbf_tps_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
 static const gsl_sinterp_type simplex_type = {"linear-simplex", 3, &simplex_alloc, &simplex_init, &simplex_eval_many, &simplex_eval_resident, &simplex_free};
 static const gsl_sinterp_type wendland_type = {"rbf-wendland-c2", 1, &rbf_wendland_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
+static const gsl_sinterp_type krige_type = {"ordinary-kriging-gaussian", 1, &krige_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
+const gsl_sinterp_type *gsl_sinterp_kriging = &krige_type;
 const gsl_sinterp_type *gsl_sinterp_rbf_wendland = &wendland_type;
 const gsl_sinterp_type *gsl_sinterp_rbf_gaussian = &gauss_type;
 const gsl_sinterp_type *gsl_sinterp_rbf_tps = &tps_type;
@@ -863,6 +886,25 @@ int gsl_sinterp_set_shape(gsl_sinterp *interp, double eps)
 {
   if (!interp) GSL_ERROR("gsl_sinterp_set_shape: null interpolant", GSL_EFAULT);
   interp->shape = eps;
+  return GSL_SUCCESS;
+}
+
+int gsl_sinterp_set_nugget(gsl_sinterp *interp, double nugget)
+{
+  if (!interp) GSL_ERROR("gsl_sinterp_set_nugget: null interpolant", GSL_EFAULT);
+  if (interp->type != &krige_type) GSL_ERROR("gsl_sinterp_set_nugget: kriging interpolants only", GSL_EINVAL);
+  if (!(nugget >= 0.0)) GSL_ERROR("gsl_sinterp_set_nugget: the nugget must be >= 0", GSL_EDOM);
+  interp->nugget = nugget;
+  return GSL_SUCCESS;
+}
+
+int gsl_sinterp_mean(const gsl_sinterp *interp, double *mean)
+{
+  if (!interp || !mean) GSL_ERROR("gsl_sinterp_mean: null argument", GSL_EFAULT);
+  if (interp->type != &krige_type) GSL_ERROR("gsl_sinterp_mean: kriging interpolants only", GSL_EINVAL);
+  const rbf_state *st = (const rbf_state *)interp->state;
+  if (!st->d_w) GSL_ERROR("gsl_sinterp_mean: interpolant not initialised", GSL_EINVAL);
+  *mean = st->mean;
   return GSL_SUCCESS;
 }
 
@@ -1051,7 +1093,10 @@ int gsl_sinterp_fprintf_grid(FILE *stream, const gsl_vector *min, const gsl_vect
 /* ======================================================================== */
 static const char INTERP_MAGIC[8] = {'G', 'S', 'L', 'S', 'I', 'N', 'T', '1'};
 
-static int type_id(const gsl_sinterp_type *T) { return T == &gauss_type ? 0 : (T == &tps_type ? 1 : (T == &wendland_type ? 3 : 2)); }
+static int type_id(const gsl_sinterp_type *T)
+{
+  return T == &gauss_type ? 0 : (T == &tps_type ? 1 : (T == &wendland_type ? 3 : (T == &krige_type ? 4 : 2)));
+}
 
 int gsl_sinterp_fwrite(FILE *stream, const gsl_sinterp *interp)
 {
@@ -1079,7 +1124,8 @@ int gsl_sinterp_fwrite(FILE *stream, const gsl_sinterp *interp)
   double *h = (double *)malloc(cnt * sizeof(double));
   if (!h) GSL_ERROR("gsl_sinterp_fwrite: out of memory", GSL_ENOMEM);
   int s = gsl_sinterp_hip_d2h(st->ctx, h, st->d_x, cnt * sizeof(double));      /* the model buffer: [centres | weights] */
-  const int64_t flags = 0;
+  int64_t flags = 0;
+  if (st->krige) memcpy(&flags, &st->mean, sizeof flags);                       /* kriging: the word carries the mean's bits */
   if (!s && (fwrite(INTERP_MAGIC, 1, 8, stream) != 8 || fwrite(head, sizeof head[0], 3, stream) != 3 ||
              fwrite(&st->eps, sizeof st->eps, 1, stream) != 1 || fwrite(&flags, sizeof flags, 1, stream) != 1 ||
              fwrite(h, sizeof(double), cnt, stream) != cnt)) {
@@ -1133,6 +1179,7 @@ int gsl_sinterp_fread(FILE *stream, gsl_sinterp *interp)
   int s = rbf_prepare_devices(interp, st);
   if (s) { free(h); return s; }
   st->eps = eps;
+  if (st->krige) memcpy(&st->mean, &flags, sizeof st->mean);
   st->model_id = next_model_id();
   s = gsl_sinterp_hip_h2d(st->ctx, st->d_x, h, cnt * sizeof(double));
   if (!s && st->ss.grp) s = gsl_sinterp_hip_group_broadcast(st->ss.grp, (void *const *)st->m_model, cnt * sizeof(double));

@@ -191,6 +191,39 @@ int simplex_tree_check_device(simplex_tree *tree, gsl_matrix *data, int device, 
                               long long *delaunay_violations);
 
 /* ======================================================================== */
+/* Part 2b: imported triangulations (no history DAG)                          */
+/* ======================================================================== */
+/* The reference's README:28-31 lists "import triangulations from QHull / CGAL" as future work.  Such a triangulation
+   comes as arrays: `triangles` [3 n] vertex ids = rows of `points`, `neighbours` [3 n] = triangle across the edge
+   OPPOSITE vertex k of the triangle, -1 on the hull (the convention of QHull's neighbours and of the leaves'
+   links in interpolation/linear_simplex.h:62-63).  neighbours == NULL: derived from the triangles (edge matching).
+   Evaluation is the barycentric interpolation of interp_point (linear_simplex.c:678-711) in a triangle that contains
+   the target under the closed rule of contains_point (:653-676), found on the GPU by a grid seed + a walk over the
+   neighbour links.  A target outside the triangulation gives index -1, value NaN and GSL_EDOM. */
+typedef struct simplex_mesh simplex_mesh;
+typedef struct simplex_mesh_device simplex_mesh_device;
+simplex_mesh *simplex_mesh_import(const gsl_matrix *points, const int *triangles, const int *neighbours, size_t n_triangles);
+/* the final triangulation of a built tree: its leaves without cage vertices, vertex order, neighbour links and
+   standardisation kept, so that evaluation returns the bits of the DAG path wherever the containing leaf is unique */
+simplex_mesh *simplex_mesh_from_tree(simplex_tree *tree, gsl_matrix *data);
+void simplex_mesh_free(simplex_mesh *mesh);
+size_t simplex_mesh_n_triangles(const simplex_mesh *mesh);
+size_t simplex_mesh_n_points(const simplex_mesh *mesh);
+const int *simplex_mesh_triangles(const simplex_mesh *mesh);   /* [3 n] */
+const int *simplex_mesh_neighbours(const simplex_mesh *mesh);  /* [3 n] */
+const int *simplex_mesh_tree_nodes(const simplex_mesh *mesh);  /* [n] DAG node of every triangle (from_tree), else NULL */
+void simplex_mesh_geometry(const simplex_mesh *mesh, double shift[2], double scale[2]);
+/* 0: walks that run into a hull edge are resolved by an exhaustive scan (meshes with holes / concave outlines) */
+void simplex_mesh_set_convex(simplex_mesh *mesh, int convex);
+simplex_mesh_device *simplex_mesh_device_alloc(const simplex_mesh *mesh, int device);
+void simplex_mesh_device_free(simplex_mesh_device *dev);
+int simplex_mesh_device_set_response(simplex_mesh_device *dev, const gsl_vector *response);
+int simplex_mesh_device_eval_many(simplex_mesh_device *dev, const gsl_matrix *targets, gsl_vector *values, int *triangle);
+int simplex_mesh_device_eval_resident(simplex_mesh_device *dev, const double *d_targets, size_t m, size_t ttda,
+                                      double *d_values, int *d_triangle);
+gsl_sinterp_hip_ctx *simplex_mesh_device_ctx(simplex_mesh_device *dev);
+
+/* ======================================================================== */
 /* Part 3: gsl_sinterp facade                                                */
 /* ======================================================================== */
 typedef struct gsl_sinterp_struct gsl_sinterp;
@@ -222,12 +255,17 @@ struct gsl_sinterp_struct {
   int want_rcond;    /* estimate the reciprocal condition number at init (Cholesky solvers)  */
   double rcond;      /* the estimate of the last init, NaN when none was made                */
   int route;         /* solver route the last init took (gsl_sinterp_hip_rbf_solve_ex)       */
+  double nugget;     /* kriging: added to the diagonal of the covariance matrix (>= 0, default 0) */
 };
 
 extern const gsl_sinterp_type *gsl_sinterp_rbf_gaussian;
 extern const gsl_sinterp_type *gsl_sinterp_rbf_tps;
 extern const gsl_sinterp_type *gsl_sinterp_rbf_wendland;    /* compactly supported C2 kernel (README:18-26 future list) */
 extern const gsl_sinterp_type *gsl_sinterp_linear_simplex;
+/* ordinary kriging with a Gaussian covariance exp(-(eps h)^2) and an optional nugget (README:24 future list):
+   s(y) = mu + sum_j w_j C(|y - x_j|) with [C + nugget I, 1; 1^T, 0] [w; mu] = [f; 0].  nugget = 0 interpolates the data,
+   nugget > 0 smooths (s(x_i) = f_i - nugget w_i); far from the data s -> mu.  gsl_sinterp_set_shape sets eps. */
+extern const gsl_sinterp_type *gsl_sinterp_kriging;
 
 gsl_sinterp *gsl_sinterp_alloc(const gsl_sinterp_type *T, size_t dim, size_t size);
 int gsl_sinterp_set_device(gsl_sinterp *interp, int device);
@@ -245,6 +283,8 @@ int gsl_sinterp_set_shape(gsl_sinterp *interp, double eps);
    _LU_REFINE pivoted LU plus one refinement step.  gsl_sinterp_set_rcond(interp, 1) makes the next init estimate
    the reciprocal condition number of the kernel matrix (Cholesky solvers; gsl_linalg_cholesky_rcond), read back
    with gsl_sinterp_rcond (GSL_EINVAL when none is available). */
+int gsl_sinterp_set_nugget(gsl_sinterp *interp, double nugget);     /* kriging type only (GSL_EINVAL otherwise) */
+int gsl_sinterp_mean(const gsl_sinterp *interp, double *mean);     /* the estimated mean mu of an initialised kriging interpolant */
 int gsl_sinterp_set_solver(gsl_sinterp *interp, int solver);
 int gsl_sinterp_set_rcond(gsl_sinterp *interp, int want);
 int gsl_sinterp_rcond(const gsl_sinterp *interp, double *rcond);

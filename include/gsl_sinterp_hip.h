@@ -114,6 +114,17 @@ int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void 
                               const double *d_targets, size_t m, size_t ttda, double *d_values,
                               int *d_leaf, long long *h_n_outside);
 
+/* Imported triangulation (no DAG): records + seed grid, then locate + interpolate.  d_tri / d_nbr [3 n_tri] (vertex ids =
+   rows of d_points; neighbour across the edge opposite vertex k, -1 = hull), d_points [2 n_points] in ROW order,
+   h_geom[8] = shift(2), scale(2), bounding box lo0, lo1, hi0, hi1 of the points; G: cells per axis of the seed grid,
+   d_seed: 2 G^2 ints.  Leaf table: gsl_sinterp_hip_tree_bind with d_pidx = d_tri.  convex = 0: a walk stopped by a
+   hull edge is resolved by an exhaustive scan instead of "outside". */
+int gsl_sinterp_hip_mesh_pack(gsl_sinterp_hip_ctx *ctx, int n_tri, const int *d_tri, const int *d_nbr, int n_points,
+                              const double *d_points, const double *h_geom, int G, void *d_records, int *d_seed);
+int gsl_sinterp_hip_mesh_eval(gsl_sinterp_hip_ctx *ctx, int n_tri, const void *d_records, const void *d_leaftab,
+                              const int *d_seed, int G, const double *h_geom, int convex, const double *d_targets,
+                              size_t m, size_t ttda, double *d_values, int *d_tri, long long *h_n_outside);
+
 /* Device-side integrity checks of a DAG given as raw arrays (same arguments as tree_pack):
    what & 1: _check_leaf_nodes  (interpolation/linear_simplex_integrity_check.c:62-119), one thread per leaf;
    what & 2: _check_delaunay    (:134-160; circumsphere per linear_simplex.c:555-605), leaves x points.
@@ -196,6 +207,16 @@ int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, double eps, co
 int gsl_sinterp_hip_rbf_solve_ex(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim,
                                  size_t xtda, double *d_phi, size_t lda, double *d_w, int solver, double *h_rcond,
                                  int *h_route);
+
+/* Ordinary kriging on a positive definite kernel used as covariance (GAUSSIAN or WENDLAND) with a nugget >= 0 (the
+   reference's README:24 future list): d_w holds f on entry and the dual weights w on exit, *h_mean the estimated
+   mean mu; s(y) = mu + sum_j w_j phi(|y - x_j|) (gsl_sinterp_hip_krige_eval = the RBF sweep + mu).  Route 7: Cholesky
+   of K = Phi + nugget I with two right-hand sides; route 8: pivoted LDL^T when K is only semi-definite. */
+int gsl_sinterp_hip_krige_solve(gsl_sinterp_hip_ctx *ctx, int kind, double eps, double nugget, const double *d_x, size_t n,
+                                int dim, size_t xtda, double *d_phi, size_t lda, double *d_w, double *h_mean, int *h_route);
+int gsl_sinterp_hip_krige_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, double mean, const double *d_x, size_t n,
+                               int dim, size_t xtda, const double *d_w, const double *d_y, size_t m, size_t ytda,
+                               double *d_s, unsigned long long model_id);
 
 /* Level-3 building block of both factorisations, exposed for tests and roofline
    measurement (role of gsl_blas_dgemm / dsyrk, blas/blas.c:1334,1649):

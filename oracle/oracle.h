@@ -126,6 +126,17 @@ int oracle_output_triangulation(oracle_tree *t, const double *data, size_t tda, 
                                 int standardize_output, const char *lines_filename, const char *points_filename,
                                 const char *circles_filename);
 
+/* imported triangulations (no reference walk exists: parity unpinned); the reference's per-triangle arithmetic on
+   explicit vertex rows `tri[3]` (the LAST one is the origin), linear_simplex.c:607-711 */
+int oracle_mesh_coords(const double *data, size_t tda, const double *shift, const double *scale, const int *tri,
+                       const double *point, double *coords);
+int oracle_mesh_contains(const double *data, size_t tda, const double *shift, const double *scale, const int *tri,
+                         const double *point);
+double oracle_mesh_interp(const double *data, size_t tda, const double *shift, const double *scale, const int *tri,
+                          const double *response, size_t rstride, const double *point);
+int oracle_mesh_locate(const double *data, size_t tda, const double *shift, const double *scale, const int *tris, size_t nt,
+                       const double *point, int *n_containing);
+
 /* ======================= RBF harness (oracle_rbf.c) ================== */
 #define ORACLE_RBF_GAUSSIAN 0   /* phi = exp(-(eps r)^2)                    */
 #define ORACLE_RBF_TPS 1        /* phi = r^2 ln r = 0.5 r^2 ln r^2, phi(0)=0 */
@@ -138,6 +149,13 @@ int oracle_rbf_solve(int kind, double eps, const double *x, size_t n, int dim, s
                      const double *f, double *w);
 void oracle_rbf_eval(int kind, double eps, const double *x, size_t n, int dim, size_t tda,
                      const double *w, const double *y, size_t m, size_t ytda, double *s);
+
+/* ordinary kriging (dual form) on the same kernels: K = Phi + nugget I, Cholesky (pivoted LDL^T when K is only
+   semi-definite); no reference code (README:24), parity unpinned */
+int oracle_krige_solve(int kind, double eps, double nugget, const double *x, size_t n, int dim, size_t tda,
+                       const double *f, double *w, double *mean);
+void oracle_krige_eval(int kind, double eps, double mean, const double *x, size_t n, int dim, size_t tda,
+                       const double *w, const double *y, size_t m, size_t ytda, double *s);
 
 /* ======================= synthetic inputs (oracle_synth.c) =========== */
 /* u(k) = (splitmix64(seed ^ k) >> 11) * 2^-53 */

@@ -74,3 +74,46 @@ void oracle_rbf_eval(int kind, double eps, const double *x, size_t n, int dim, s
     s[k] = acc;
   }
 }
+
+/* Ordinary kriging with covariance C(h) = phi(h) and nugget eta (README:24 lists kriging as future work: no
+   reference code, PARITY UNPINNED; the solver underneath is the pinned gsl_linalg_cholesky_decomp1 + _svx, with
+   gsl_linalg_pcholesky_decomp + _svx as the semi-definite fall-back).  Dual form:
+       [K 1; 1^T 0] [w; mu] = [f; 0],  K = Phi + eta I      ->  a = K^-1 f, b = K^-1 1, mu = (1^T a) / (1^T b), w = a - mu b
+       s(y) = mu + sum_j w_j phi(|y - x_j|)                                                                          */
+int oracle_krige_solve(int kind, double eps, double nugget, const double *x, size_t n, int dim, size_t tda,
+                       const double *f, double *w, double *mean)
+{
+  double *phi = (double *)malloc(n * n * sizeof(double)), *b = (double *)malloc(n * sizeof(double));
+  if (!phi || !b) { free(phi); free(b); return ORACLE_FAILURE; }
+  oracle_rbf_fill(kind, eps, x, n, dim, tda, phi, n);
+  for (size_t i = 0; i < n; i++) { phi[i * n + i] += nugget; b[i] = 1.0; }
+  memcpy(w, f, n * sizeof(double));
+  int status = oracle_cholesky_decomp1(n, phi, n);
+  if (status == ORACLE_SUCCESS) {
+    oracle_cholesky_svx(n, phi, n, w);
+    oracle_cholesky_svx(n, phi, n, b);
+  } else {                                            /* semi-definite: pivoted LDL^T (linalg/pcholesky.c:71-229) */
+    size_t *perm = (size_t *)malloc(n * sizeof(size_t));
+    oracle_rbf_fill(kind, eps, x, n, dim, tda, phi, n);
+    for (size_t i = 0; i < n; i++) phi[i * n + i] += nugget;
+    status = oracle_pcholesky_decomp(n, phi, n, perm);
+    if (status == ORACLE_SUCCESS) { oracle_pcholesky_svx(n, phi, n, perm, w); oracle_pcholesky_svx(n, phi, n, perm, b); }
+    free(perm);
+  }
+  if (status == ORACLE_SUCCESS) {
+    double sa = 0.0, sb = 0.0;
+    for (size_t i = 0; i < n; i++) { sa += w[i]; sb += b[i]; }
+    const double mu = sa / sb;
+    for (size_t i = 0; i < n; i++) w[i] = w[i] - mu * b[i];
+    *mean = mu;
+  }
+  free(phi); free(b);
+  return status;
+}
+
+void oracle_krige_eval(int kind, double eps, double mean, const double *x, size_t n, int dim, size_t tda,
+                       const double *w, const double *y, size_t m, size_t ytda, double *s)
+{
+  oracle_rbf_eval(kind, eps, x, n, dim, tda, w, y, m, ytda, s);
+  for (size_t k = 0; k < m; k++) s[k] = s[k] + mean;
+}

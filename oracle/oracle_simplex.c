@@ -708,3 +708,72 @@ uint64_t oracle_tree_hash(const oracle_tree *t)
 #undef MIX
   return h;
 }
+
+/* ---------------------------------------------------------------------- */
+/* Imported triangulations (README:28-31: future work in the reference, so there is no reference walk: PARITY
+   UNPINNED).  What the reference fixes is the per-triangle arithmetic, restated here on explicit vertices:
+   calculate_bary_coords (linear_simplex.c:607-651: matrix of standardised edge vectors wrt the LAST vertex,
+   gsl_linalg_LU_decomp + _svx), contains_point's closed rule (:653-676) and interp_point (:678-711).          */
+int oracle_mesh_coords(const double *data, size_t tda, const double *shift, const double *scale, const int *tri,
+                       const double *point, double *coords)
+{
+  const int dim = 2;
+  const double *x0 = data + (size_t)tri[dim] * tda;
+  double mat[4];
+  size_t perm[2];
+  int signum;
+  for (int i = 0; i < dim; i++) {
+    const double *p = data + (size_t)tri[i] * tda;
+    for (int j = 0; j < dim; j++) {
+      double pv = scale[j] * (p[j] - shift[j]);
+      double xv = scale[j] * (x0[j] - shift[j]);
+      mat[(size_t)j * dim + i] = pv - xv;                /* :633 */
+    }
+  }
+  oracle_lu_decomp(dim, mat, dim, perm, &signum);
+  if (oracle_lu_singular(dim, mat, dim)) return ORACLE_FAILURE;
+  double pp[2];
+  for (int j = 0; j < dim; j++) {                        /* :645-647 */
+    double v = point[j];
+    v = v - x0[j];
+    v = v * scale[j];
+    pp[j] = v;
+  }
+  oracle_lu_svx(dim, mat, dim, perm, pp);
+  coords[0] = pp[0]; coords[1] = pp[1];
+  return ORACLE_SUCCESS;
+}
+
+int oracle_mesh_contains(const double *data, size_t tda, const double *shift, const double *scale, const int *tri,
+                         const double *point)
+{
+  double c[2], tot = 0;
+  if (oracle_mesh_coords(data, tda, shift, scale, tri, point, c) != ORACLE_SUCCESS) return 0;
+  for (int i = 0; i < 2; i++) {
+    tot += c[i];
+    if ((c[i] < 0) || (c[i] > 1)) return 0;
+  }
+  if ((tot < 0) || (tot > 1)) return 0;
+  return 1;
+}
+
+double oracle_mesh_interp(const double *data, size_t tda, const double *shift, const double *scale, const int *tri,
+                          const double *response, size_t rstride, const double *point)
+{
+  double c[2], tot = 0, interp = 0;
+  oracle_mesh_coords(data, tda, shift, scale, tri, point, c);
+  for (int i = 0; i < 2; i++) { tot += c[i]; interp += c[i] * response[(size_t)tri[i] * rstride]; }
+  interp += (1 - tot) * response[(size_t)tri[2] * rstride];
+  return interp;
+}
+
+/* exhaustive search: smallest index of a containing triangle (-1: none); *n_containing counts them */
+int oracle_mesh_locate(const double *data, size_t tda, const double *shift, const double *scale, const int *tris, size_t nt,
+                       const double *point, int *n_containing)
+{
+  int first = -1, cnt = 0;
+  for (size_t t = 0; t < nt; t++)
+    if (oracle_mesh_contains(data, tda, shift, scale, tris + 3 * t, point)) { if (first < 0) first = (int)t; cnt++; }
+  if (n_containing) *n_containing = cnt;
+  return first;
+}

@@ -41,6 +41,7 @@ def lib():
         L.oracle_mt_uniform_int.argtypes = [C.c_void_p, C.c_ulong]
         L.oracle_mt_free.argtypes = [C.c_void_p]
         L.oracle_interp_point.restype = C.c_double
+        L.oracle_mesh_interp.restype = C.c_double
         L.oracle_tree_hash.restype = C.c_uint64
         L.oracle_rbf_phi.restype = C.c_double
         L.oracle_rbf_phi.argtypes = [C.c_int, C.c_double, C.c_double]
@@ -239,6 +240,20 @@ def rbf_solve(kind, eps, x, f):
     return w
 
 
+def krige_solve(kind, eps, nugget, x, f):
+    n, d = x.shape
+    w = np.empty(n)
+    mu = C.c_double(0)
+    st = lib().oracle_krige_solve(kind, C.c_double(eps), C.c_double(nugget), _p(x), _sz(n), d, _sz(x.strides[0] // 8), _p(f), _p(w),
+                                  C.byref(mu))
+    assert st == 0, st
+    return w, mu.value
+
+
+def krige_eval(kind, eps, mean, x, w, y):
+    return rbf_eval(kind, eps, x, w, y) + mean
+
+
 def rbf_eval(kind, eps, x, w, y):
     n, d = x.shape
     m = y.shape[0]
@@ -269,3 +284,33 @@ def synth_response(x):
 
 def gaussian_eps(n, dim):
     return 2.0 * n ** (1.0 / dim)
+
+
+# ---- imported triangulations: the reference's per-triangle arithmetic on explicit vertex rows
+def mesh_contains(data, shift, scale, tri, point):
+    d = np.ascontiguousarray(data, dtype=np.float64)
+    t = np.ascontiguousarray(tri, dtype=np.int32)
+    return bool(lib().oracle_mesh_contains(_p(d), _sz(d.shape[1]), _p(np.ascontiguousarray(shift, dtype=np.float64)),
+                                           _p(np.ascontiguousarray(scale, dtype=np.float64)),
+                                           t.ctypes.data_as(C.POINTER(C.c_int)), _p(np.ascontiguousarray(point, dtype=np.float64))))
+
+
+def mesh_interp(data, shift, scale, tri, response, point):
+    d = np.ascontiguousarray(data, dtype=np.float64)
+    t = np.ascontiguousarray(tri, dtype=np.int32)
+    r = np.ascontiguousarray(response, dtype=np.float64)
+    return float(lib().oracle_mesh_interp(_p(d), _sz(d.shape[1]), _p(np.ascontiguousarray(shift, dtype=np.float64)),
+                                          _p(np.ascontiguousarray(scale, dtype=np.float64)),
+                                          t.ctypes.data_as(C.POINTER(C.c_int)), _p(r), _sz(1),
+                                          _p(np.ascontiguousarray(point, dtype=np.float64))))
+
+
+def mesh_locate(data, shift, scale, tris, point):
+    """(smallest containing triangle or -1, number of containing triangles) by exhaustive search"""
+    d = np.ascontiguousarray(data, dtype=np.float64)
+    t = np.ascontiguousarray(tris, dtype=np.int32)
+    n = C.c_int(0)
+    first = lib().oracle_mesh_locate(_p(d), _sz(d.shape[1]), _p(np.ascontiguousarray(shift, dtype=np.float64)),
+                                     _p(np.ascontiguousarray(scale, dtype=np.float64)), t.ctypes.data_as(C.POINTER(C.c_int)),
+                                     _sz(len(t)), _p(np.ascontiguousarray(point, dtype=np.float64)), C.byref(n))
+    return int(first), n.value

@@ -1,0 +1,56 @@
+"""Imported triangulations (the tail of row 4 + the leaf-adjacency walk of row 1; README:28-31 of the
+reference lists the import as future work, so there is no reference walk: PARITY UNPINNED for the locate step --
+the per-triangle arithmetic is the reference's and is checked against its restatement on explicit vertices,
+oracle_mesh_*).  CPU part: validation and neighbour derivation; -m gpu part: tests/test_gpu_mesh.py."""
+import numpy as np
+import pytest
+
+
+def qhull(points):
+    from scipy.spatial import Delaunay
+    d = Delaunay(points)
+    return d, d.simplices.astype(np.int32), d.neighbors.astype(np.int32)
+
+
+def test_import_derives_qhull_neighbours(pkg, orc):
+    x = orc.synth_centres(500, 2)
+    _, tri, nbr = qhull(x)
+    given = pkg.SimplexMesh.from_arrays(x, tri, nbr)
+    derived = pkg.SimplexMesh.from_arrays(x, tri)               # neighbours == NULL: edge matching
+    assert given.n_triangles == len(tri)
+    assert np.array_equal(given.neighbours(), nbr) and np.array_equal(derived.neighbours(), nbr)
+    assert np.array_equal(derived.triangles(), tri) and derived.tree_nodes() is None
+
+
+def test_import_rejects_bad_arrays(pkg, orc):
+    x = orc.synth_centres(50, 2)
+    _, tri, nbr = qhull(x)
+    for bad_tri, bad_nbr in ((np.where(tri == 0, 99, tri), nbr),                       # vertex id out of range
+                             (tri, np.where(nbr == nbr.max(), len(tri) + 3, nbr)),     # neighbour id out of range
+                             (np.vstack([tri[0][[0, 0, 2]], tri[1:]]), None),          # repeated vertex
+                             (tri, np.roll(nbr, 1, axis=1))):                          # links not mutual / wrong edge
+        with pytest.raises(pkg.capi.GslError):
+            pkg.SimplexMesh.from_arrays(x, bad_tri, bad_nbr)
+    with pytest.raises(pkg.capi.GslError):
+        pkg.SimplexMesh.from_arrays(x, np.vstack([tri, tri[:1], tri[:1]]))             # an edge shared by three triangles
+
+
+def test_export_of_a_tree_keeps_leaves_and_links(pkg, orc):
+    n = 400
+    x = orc.synth_centres(n, 2)
+    t = pkg.SimplexTree(2, n)
+    assert t.init(x, flags=0, rng=pkg.capi.Rng(0)) == 0
+    mesh = pkg.SimplexMesh.from_tree(t)
+    types, pidx, links = t.arrays()
+    sh = t.shuffle()
+    nodes, tri, nbr = mesh.tree_nodes(), mesh.triangles(), mesh.neighbours()
+    leaves_in_hull = [k for k in range(t.n_nodes) if types[k] == 0 and (pidx.reshape(-1, 3)[k] >= 0).all()]
+    assert list(nodes) == leaves_in_hull                         # every leaf made of data points, in node order
+    assert np.array_equal(tri, sh[pidx.reshape(-1, 3)[nodes]])   # same vertex ORDER, insertion index -> data row
+    where = {int(k): i for i, k in enumerate(nodes)}
+    want = np.array([[where.get(int(l), -1) if l > 0 else -1 for l in links.reshape(-1, 3)[k]] for k in nodes])
+    assert np.array_equal(nbr, want)
+    # Euler: a triangulation of n points with h >= 3 hull vertices has 2n - 2 - h triangles
+    assert mesh.n_triangles <= 2 * n - 5
+    shift, scale = mesh.geometry()
+    assert np.array_equal(np.concatenate([shift, scale]), t.geom()[6:10])
