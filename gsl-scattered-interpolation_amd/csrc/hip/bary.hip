@@ -1057,6 +1057,8 @@ __global__ void mesh_seed_kernel(int n_tri, const int *__restrict__ tri, int n_p
 }
 
 #define MESH_SEED_RINGS 8
+#define MESH_GAP 1e-9   /* a target within this much (standardised barycentric units) of a triangle that no triangle contains
+                           under the floating-point closed test is given to the least violating triangle */
 __global__ void mesh_seed_fill_kernel(const int *__restrict__ seed_in, int *__restrict__ seed_out, int G)
 {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1104,6 +1106,8 @@ mesh_walk_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__re
   int found = -2;                                              /* -2 walking, -1 outside, -3 exhaustive scan */
   if (!(y0 == y0 && y1 == y1)) found = -1;                     /* NaN target: outside, like the DAG path */
   NodeRec cur;
+  int prev = -1;
+  double prev_viol = 0.0;
   for (int step = 0; found == -2; step++) {
     if (step >= max_steps || t < 0 || t >= n_tri) { found = -3; break; }
     cur = load_rec(rec, t);
@@ -1121,7 +1125,23 @@ mesh_walk_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__re
     int next = -1;
     for (int a = 0; a < 3 && next < 0; a++)
       if (v[order[a]] < 0.0 && cur.child[order[a]] >= 0) next = cur.child[order[a]];
-    if (next < 0) { found = (v[order[0]] < 0.0 && convex) ? -1 : -3; break; }      /* only hull edges in the way */
+    const double viol = violation(c0, c1);
+    if (next < 0) {                                            /* only hull edges in the way */
+      if (viol <= MESH_GAP) found = t;                         /* ... and the target within rounding of one: it is this triangle's */
+      else found = (v[order[0]] < 0.0 && convex) ? -1 : -3;
+      break;
+    }
+    if (next == prev) {
+      /* both triangles of an edge send the target across it: the target lies within rounding of the edge and the
+         floating-point closed test fails on both sides (the gap the reference's walk closes with its "least violating
+         child", linear_simplex.c:374-400).  Same rule: the less violating of the two, the smaller index on a tie;
+         anything beyond rounding size goes to the exhaustive scan. */
+      const bool take_prev = prev_viol < viol || (prev_viol == viol && prev < t);
+      if ((take_prev ? prev_viol : viol) <= MESH_GAP) { found = take_prev ? prev : t; if (take_prev) cur = load_rec(rec, prev); }
+      else found = -3;
+      break;
+    }
+    prev = t; prev_viol = viol;
     t = next;
   }
   if (found >= 0) { mesh_finish(cur, tab, found, y0, y1, s0, s1, k, values, tri_out); return; }
@@ -1135,31 +1155,38 @@ mesh_walk_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__re
   atomicAdd(n_outside, 1ULL);
 }
 
-/* exhaustive scan: one workgroup per queued target, smallest index of a containing triangle */
+/* exhaustive scan: one workgroup per queued target; the least violating triangle (0 = containing), smallest index on a
+   tie, accepted up to MESH_GAP */
 __global__ void __launch_bounds__(256)
 mesh_scan_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, double s0, double s1,
                  const double *__restrict__ targets, size_t ttda, double *__restrict__ values, int *__restrict__ tri_out,
                  unsigned long long *__restrict__ n_outside, const unsigned *__restrict__ todo)
 {
+  __shared__ unsigned long long s_viol;
   __shared__ int s_best;
   const unsigned count = todo[0];
   for (unsigned q = blockIdx.x; q < count; q += gridDim.x) {
     const size_t k = todo[1 + q];
     const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
-    if (threadIdx.x == 0) s_best = 0x7fffffff;
+    if (threadIdx.x == 0) { s_viol = ~0ULL; s_best = 0x7fffffff; }
     __syncthreads();
-    int best = 0x7fffffff;
-    for (int t = threadIdx.x; t < n_tri && t < best; t += blockDim.x) {
+    double my_viol = INFINITY;
+    int my_t = 0x7fffffff;
+    for (int t = threadIdx.x; t < n_tri; t += blockDim.x) {
       const NodeRec r = load_rec(rec, t);
       double c0, c1;
       solve_node(r, y0, y1, s0, s1, c0, c1);
-      if (!META_SINGULAR(r.meta) && inside_unit(c0, c1)) best = t;
+      if (META_SINGULAR(r.meta) || !(c0 == c0 && c1 == c1)) continue;
+      const double viol = inside_unit(c0, c1) ? 0.0 : violation(c0, c1);
+      if (viol < my_viol) { my_viol = viol; my_t = t; }          /* ascending t: the first of equal violations stays */
     }
-    if (best != 0x7fffffff) atomicMin(&s_best, best);
+    if (my_t != 0x7fffffff) atomicMin(&s_viol, (unsigned long long)__double_as_longlong(my_viol));   /* viol >= 0: bits ordered */
+    __syncthreads();
+    if (my_t != 0x7fffffff && (unsigned long long)__double_as_longlong(my_viol) == s_viol) atomicMin(&s_best, my_t);
     __syncthreads();
     if (threadIdx.x == 0) {
       const int t = s_best;
-      if (t != 0x7fffffff) mesh_finish(load_rec(rec, t), tab, t, y0, y1, s0, s1, k, values, tri_out);
+      if (t != 0x7fffffff && __longlong_as_double((long long)s_viol) <= MESH_GAP) mesh_finish(load_rec(rec, t), tab, t, y0, y1, s0, s1, k, values, tri_out);
       else {
         values[k] = __longlong_as_double(0x7ff8000000000000LL);
         if (tri_out) tri_out[k] = -1;

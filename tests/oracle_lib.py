@@ -295,6 +295,16 @@ def mesh_contains(data, shift, scale, tri, point):
                                            t.ctypes.data_as(C.POINTER(C.c_int)), _p(np.ascontiguousarray(point, dtype=np.float64))))
 
 
+def mesh_coords(data, shift, scale, tri, point):
+    d = np.ascontiguousarray(data, dtype=np.float64)
+    t = np.ascontiguousarray(tri, dtype=np.int32)
+    c = np.zeros(2)
+    lib().oracle_mesh_coords(_p(d), _sz(d.shape[1]), _p(np.ascontiguousarray(shift, dtype=np.float64)),
+                             _p(np.ascontiguousarray(scale, dtype=np.float64)), t.ctypes.data_as(C.POINTER(C.c_int)),
+                             _p(np.ascontiguousarray(point, dtype=np.float64)), _p(c))
+    return c
+
+
 def mesh_interp(data, shift, scale, tri, response, point):
     d = np.ascontiguousarray(data, dtype=np.float64)
     t = np.ascontiguousarray(tri, dtype=np.int32)

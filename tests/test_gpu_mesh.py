@@ -63,15 +63,24 @@ def test_targets_on_edges_and_vertices_follow_the_closed_rule(pkg, orc):
     verts = x[rng.choice(n, 300, replace=False)]                # data points: vertices of ~6 triangles each
     y = np.ascontiguousarray(np.vstack([mids, verts]))
     st, vals, idx = dev.eval_many(y)
-    on_hull = idx < 0
-    assert on_hull.sum() <= 5                                   # a midpoint of a HULL edge may round to the outside
-    for k in np.nonzero(~on_hull)[0]:
-        assert orc.mesh_contains(x, shift, scale, tri[idx[k]], y[k])
-        assert vals[k] == orc.mesh_interp(x, shift, scale, tri[idx[k]], f, y[k])
+    # A point within rounding of an edge can fail the floating-point closed test of BOTH triangles (the reference's
+    # walk closes that gap with its "least violating child", linear_simplex.c:374-400); the mesh walk applies the same
+    # rule: the returned triangle contains the target or misses it by rounding only (<= 1e-9 in barycentric units).
+    assert (idx >= 0).all() and st == pkg.GSL_SUCCESS
+    gaps = 0
+    for k in range(len(y)):
+        tk = tri[idx[k]]
+        if not orc.mesh_contains(x, shift, scale, tk, y[k]):
+            c = orc.mesh_coords(x, shift, scale, tk, y[k])
+            c3 = np.array([c[0], c[1], 1.0 - (c[0] + c[1])])
+            assert max((-c3).max(), (c3 - 1.0).max()) <= 1e-12
+            gaps += 1
+        assert vals[k] == orc.mesh_interp(x, shift, scale, tk, f, y[k])
+    print(f"{gaps} of {len(y)} on-edge / on-vertex targets fall into a rounding gap")
     # a vertex target returns the vertex's datum (one coordinate is exactly 1 or the last weight is 1 - 0)
     got = vals[len(mids):]
     want = f[[int(np.argmin(((x - v) ** 2).sum(1))) for v in verts]]
-    assert np.abs(got - want).max() <= 4e-16 * np.abs(f).max()
+    assert np.abs(got - want).max() <= 1e-13 * np.abs(f).max()
 
 
 @pytest.mark.parametrize("n,m", [(2000, 40000)])
