@@ -842,86 +842,52 @@ extern "C" int gsl_sinterp_hip_tree_bind(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   return ST_SUCCESS;
 }
 
-extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_records,
-                                         const void *d_leaftab, const double *h_scale, const double *d_targets,
-                                         size_t m, size_t ttda, double *d_values, int *d_leaf,
-                                         long long *h_n_outside)
+/* One batch (or one chunk of a batch) on ctx->stream.  wrec != NULL: the certified walk with these records (built by
+   the caller), the walker lists / queue in the section `wslot` of the walk buffer; slot: section of the sort buffer
+   (-1: the whole buffer); m_cap: the largest chunk of the batch (sizes the sections); inner_side: the finish kernel
+   may run on the context's side stream (only when the caller does not use that stream for another chunk). */
+static int bary_eval_part(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_records, const void *d_leaftab, const double *h_scale,
+                          const double *d_targets, size_t m, size_t ttda, double *d_values, int *d_leaf, unsigned long long *d_count,
+                          const WalkRec *wrec, char *wsec, size_t m_cap, int slot, bool inner_side)
 {
-  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
-  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
-  REQUIRE(ctx, n_nodes > 0 && ttda >= 2, ST_EINVAL);
-  REQUIRE(ctx, d_records && d_leaftab && h_scale && (m == 0 || (d_targets && d_values)), ST_EFAULT);
-  if (h_n_outside) *h_n_outside = 0;
-  if (m == 0) return ST_SUCCESS;
-  unsigned long long *d_count = (unsigned long long *)ctx->d_scratch;
-  HIP_OK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
-  /* m >= 4096: the targets are gathered into grid-cell order, swept contiguously, and the results
-     un-sorted afterwards (see sinterp_sort_reorder) */
   static const bool no_fast = getenv("GSL_SINTERP_NO_FASTDIV") && getenv("GSL_SINTERP_NO_FASTDIV")[0] == '1';
-  static const bool no_affine = getenv("GSL_SINTERP_NO_AFFINE_WALK") && getenv("GSL_SINTERP_NO_AFFINE_WALK")[0] == '1';
-  static const bool no_side = getenv("GSL_SINTERP_NO_SIDE_STREAM") && getenv("GSL_SINTERP_NO_SIDE_STREAM")[0] == '1';
   const bool will_sort = m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1');
-  /* Large batches: per-batch affine walk records (a pass over the node records: ~n_nodes x 128 bytes) and the
-     certified walk; what it could not certify is queued for the exact kernel.  The results do not depend on
-     which kernel walked a target. */
-  const bool use_walk = !no_fast && !no_affine && will_sort && m < 0x7fffffffULL && m >= (size_t)n_nodes / 8;
+  const bool use_walk = wrec != NULL;
   const unsigned n_slices = (unsigned)((m + WALK_SLICE - 1) / WALK_SLICE);
-  WalkRec *wrec = NULL;
   unsigned *todo_count = NULL;
   int *todo = NULL;
   WalkList wl;
   memset(&wl, 0, sizeof wl);
-  /* kernels of this evaluation that do not depend on each other run beside the main stream: the walk records are
-     built while the targets are sorted, the finish kernel runs beside the exact kernel's queue */
-  bool side = false;
   if (use_walk) {
-    const size_t mp = (size_t)n_slices * WALK_SLICE;
+    const size_t mp = ((m_cap + WALK_SLICE - 1) / WALK_SLICE) * WALK_SLICE;
     auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
-    const size_t o_cnt = up((size_t)n_nodes * sizeof(WalkRec)), o_todo = o_cnt + 64, o_y = o_todo + up(m * sizeof(int)),
-                 o_st = o_y + up(mp * sizeof(double2)), o_k = o_st + up(mp * sizeof(int4)), o_sc = o_k + up(mp * sizeof(int)),
-                 bytes = o_sc + up((size_t)n_slices * sizeof(unsigned));
-    void *wb = NULL;
-    int st = sinterp_walkbuf(ctx, bytes, &wb);
-    if (st) return st;
-    char *wbc = (char *)wb;
-    wrec = (WalkRec *)wb;
-    todo_count = (unsigned *)(wbc + o_cnt);
-    todo = (int *)(wbc + o_todo);
-    wl.y = (double2 *)(wbc + o_y); wl.st = (int4 *)(wbc + o_st); wl.k = (int *)(wbc + o_k); wl.count = (unsigned *)(wbc + o_sc);
-    if (!no_side && !ctx->side_stream) {
-      if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) ctx->side_stream = NULL;
-      for (int i = 0; i < 4 && ctx->side_stream; i++)
-        if (hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = NULL; }
-    }
-    side = !no_side && ctx->side_stream != NULL;
-    hipStream_t ps = ctx->stream;
-    if (side) {
-      HIP_OK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));          /* after whatever produced the records */
-      HIP_OK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
-      ps = ctx->side_stream;
-    }
-    HIP_OK(ctx, hipMemsetAsync(todo_count, 0, 64, ps));
-    hipLaunchKernelGGL(walk_pack_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, ps, n_nodes,
-                       (const NodeRec *)d_records, h_scale[0], h_scale[1], wrec);
-    if (side) HIP_OK(ctx, hipEventRecord(ctx->side_ev[1], ctx->side_stream));
+    const size_t o_todo = 64, o_y = o_todo + up(m_cap * sizeof(int)), o_st = o_y + up(mp * sizeof(double2)),
+                 o_k = o_st + up(mp * sizeof(int4)), o_sc = o_k + up(mp * sizeof(int));
+    todo_count = (unsigned *)wsec;
+    todo = (int *)(wsec + o_todo);
+    wl.y = (double2 *)(wsec + o_y); wl.st = (int4 *)(wsec + o_st); wl.k = (int *)(wsec + o_k); wl.count = (unsigned *)(wsec + o_sc);
+    HIP_OK(ctx, hipMemsetAsync(todo_count, 0, 64, ctx->stream));
   }
+  static const bool no_jump = getenv("GSL_SINTERP_NO_JUMP") && getenv("GSL_SINTERP_NO_JUMP")[0] == '1';
+  const bool have_table = !no_jump && ctx->jump_rec == d_records && ctx->jump_nodes == n_nodes && ctx->d_jumpt;
   sinterp_sorted srt;
   bool sorted = false;
   if (will_sort) {
-    int st = sinterp_sort_reorder(ctx, d_targets, m, ttda, 2, 64, &srt);
+    /* bin by the data's bounding box when tree_pack kept one for these records: saves the pass over the targets */
+    int st = sinterp_sort_reorder(ctx, d_targets, m, ttda, 2, 64, &srt, m_cap, slot,
+                                  have_table ? (const unsigned long long *)ctx->d_jumpt : (const unsigned long long *)NULL);
     if (st) return st;
     sorted = true;
   }
   int *d_jump = NULL;
   int G = 0;
   const unsigned long long *d_jbox = NULL;
-  static const bool no_jump = getenv("GSL_SINTERP_NO_JUMP") && getenv("GSL_SINTERP_NO_JUMP")[0] == '1';
-  if (!no_jump && ctx->jump_rec == d_records && ctx->jump_nodes == n_nodes && ctx->d_jumpt) {
+  if (have_table) {
     /* the table tree_pack built for these records on this context */
     d_jump = (int *)((char *)ctx->d_jumpt + 64);
     d_jbox = (const unsigned long long *)ctx->d_jumpt;
     G = ctx->jump_G;
-  } else if (sorted && !no_jump && n_nodes >= 2048) {
+  } else if (sorted && !no_jump && n_nodes >= 2048 && slot < 0) {
     /* records packed elsewhere (e.g. received by broadcast): a table over THIS batch's bounding box */
     /* grid fine enough that a cell is about the size of the final triangles (~n_nodes/9 points) */
     G = 32;
@@ -943,8 +909,8 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   const int packed = sorted && d_leaf != NULL;             /* {value, leaf} pairs in srt.vs, see store_result */
   const int *perm = NULL;
   const unsigned *m_dev = NULL;
+  bool side = false;
   if (use_walk) {
-    if (side) HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));     /* walk records ready */
     hipLaunchKernelGGL(bary_start_kernel, dim3(n_slices), dim3(WALK_SLICE), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
                        (const WalkRec *)wrec, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt,
                        (const int *)d_jump, G, d_jbox, todo_count, todo, wl, packed);
@@ -968,6 +934,7 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
     hipLaunchKernelGGL(bary_walk_kernel, dim3((unsigned)wblocks), dim3(64), 0, ctx->stream, (const WalkRec *)wrec, wl, n_slices,
                        todo_count, todo, (unsigned long long *)(todo_count + 2), batch);
     hipStream_t fs = ctx->stream;
+    side = inner_side && ctx->side_stream != NULL;
     if (side) {                                  /* the finish kernel beside the exact kernel (disjoint targets) */
       HIP_OK(ctx, hipEventRecord(ctx->side_ev[2], ctx->stream));
       HIP_OK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[2], 0));
@@ -989,15 +956,110 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
                        (const NodeRec *)d_records, (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], yt, m, yl, vt, lt, d_count,
                        perm, (const int *)d_jump, G, d_jbox, m_dev, packed);
   LAUNCH_CHECK(ctx);
-  if (use_walk && side) HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[3], 0));   /* join the finish kernel */
+  if (side) HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[3], 0));   /* join the finish kernel */
   if (sorted) {
     int st = packed ? sinterp_unsort_packed(ctx, &srt, m, d_values, d_leaf) : sinterp_unsort(ctx, &srt, m, d_values, d_leaf);
     if (st) return st;
   }
+  return ST_SUCCESS;
+}
+
+#define BARY_CHUNKS 4            /* pieces of a large batch, alternating between the context's two streams */
+#define BARY_CHUNK_MIN (1u << 20)
+
+extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_records,
+                                         const void *d_leaftab, const double *h_scale, const double *d_targets,
+                                         size_t m, size_t ttda, double *d_values, int *d_leaf,
+                                         long long *h_n_outside)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
+  REQUIRE(ctx, n_nodes > 0 && ttda >= 2, ST_EINVAL);
+  REQUIRE(ctx, d_records && d_leaftab && h_scale && (m == 0 || (d_targets && d_values)), ST_EFAULT);
+  if (h_n_outside) *h_n_outside = 0;
+  if (m == 0) return ST_SUCCESS;
+  unsigned long long *d_count = (unsigned long long *)ctx->d_scratch;
+  HIP_OK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+  /* m >= 4096: the targets are gathered into grid-cell order, swept contiguously, and the results
+     un-sorted afterwards (see sinterp_sort_reorder) */
+  static const bool no_fast = getenv("GSL_SINTERP_NO_FASTDIV") && getenv("GSL_SINTERP_NO_FASTDIV")[0] == '1';
+  static const bool no_affine = getenv("GSL_SINTERP_NO_AFFINE_WALK") && getenv("GSL_SINTERP_NO_AFFINE_WALK")[0] == '1';
+  static const bool no_side = getenv("GSL_SINTERP_NO_SIDE_STREAM") && getenv("GSL_SINTERP_NO_SIDE_STREAM")[0] == '1';
+  /* read per call (tests switch them inside one process): off switch, and the smallest piece worth a stream hop */
+  const bool no_chunks = getenv("GSL_SINTERP_NO_BARY_CHUNKS") && getenv("GSL_SINTERP_NO_BARY_CHUNKS")[0] == '1';
+  size_t chunk_min = BARY_CHUNK_MIN;
+  if (getenv("GSL_SINTERP_BARY_CHUNK_MIN") && atol(getenv("GSL_SINTERP_BARY_CHUNK_MIN")) >= 4096) chunk_min = (size_t)atol(getenv("GSL_SINTERP_BARY_CHUNK_MIN"));
+  const bool will_sort = m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1');
+  /* Large batches: per-batch affine walk records (a pass over the node records: ~n_nodes x 128 bytes) and the
+     certified walk; what it could not certify is queued for the exact kernel.  The results do not depend on
+     which kernel walked a target. */
+  const bool use_walk = !no_fast && !no_affine && will_sort && m < 0x7fffffffULL && m >= (size_t)n_nodes / 8;
+  if (!no_side && use_walk && !ctx->side_stream) {
+    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) ctx->side_stream = NULL;
+    for (int i = 0; i < 4 && ctx->side_stream; i++)
+      if (hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = NULL; }
+  }
+  const bool side = use_walk && !no_side && ctx->side_stream != NULL;
+  /* Pipeline (round 3).  The cell sort of the targets is bound by returning L2 atomics and scattered 16-byte stores,
+     the certified walk by dependent record gathers through L1 / the texture addressers: different units, and run
+     one after the other they each left the other's idle (0.93 ms of sorting around 0.97 ms of locating at C5).  A
+     large batch is cut into BARY_CHUNKS pieces that alternate between the context's stream and its side stream:
+     chunk i+1 is binned and gathered while chunk i walks.  Each piece has its own section of the sort and walk
+     buffers; a value depends on (records, target) only, so the split changes no bit. */
+  const int n_chunks = (side && !no_chunks && m >= (size_t)BARY_CHUNKS * chunk_min) ? BARY_CHUNKS : 1;
+  const size_t m_cap = n_chunks > 1 ? (((m + n_chunks - 1) / n_chunks + WALK_SLICE - 1) / WALK_SLICE) * WALK_SLICE : m;
+  WalkRec *wrec = NULL;
+  char *wsec[2] = {NULL, NULL};
+  if (use_walk) {
+    const size_t mp = ((m_cap + WALK_SLICE - 1) / WALK_SLICE) * WALK_SLICE;
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t o_rec = up((size_t)n_nodes * sizeof(WalkRec));
+    const size_t sec = 64 + up(m_cap * sizeof(int)) + up(mp * sizeof(double2)) + up(mp * sizeof(int4)) + up(mp * sizeof(int)) +
+                       up((mp / WALK_SLICE) * sizeof(unsigned));
+    void *wb = NULL;
+    int st = sinterp_walkbuf(ctx, o_rec + sec * (n_chunks > 1 ? 2 : 1), &wb);
+    if (st) return st;
+    wrec = (WalkRec *)wb;
+    wsec[0] = (char *)wb + o_rec;
+    wsec[1] = n_chunks > 1 ? wsec[0] + sec : wsec[0];
+    hipStream_t ps = ctx->stream;
+    if (side) {
+      HIP_OK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));          /* after whatever produced the records */
+      HIP_OK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+      ps = ctx->side_stream;
+    }
+    hipLaunchKernelGGL(walk_pack_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, ps, n_nodes,
+                       (const NodeRec *)d_records, h_scale[0], h_scale[1], wrec);
+    LAUNCH_CHECK(ctx);
+    if (side) HIP_OK(ctx, hipEventRecord(ctx->side_ev[1], ctx->side_stream));
+  }
+  int st = ST_SUCCESS;
+  if (n_chunks == 1) {
+    /* the walk records are built on the side stream while the targets are sorted on the main one; the sort comes
+       first inside bary_eval_part, so the join is placed in front of it only when there is no side stream */
+    if (side) HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));
+    st = bary_eval_part(ctx, n_nodes, d_records, d_leaftab, h_scale, d_targets, m, ttda, d_values, d_leaf, d_count, wrec, wsec[0], m_cap,
+                        -1, side);
+  } else {
+    hipStream_t main_stream = ctx->stream;
+    HIP_OK(ctx, hipStreamWaitEvent(main_stream, ctx->side_ev[1], 0));     /* walk records (the side stream is ordered behind them) */
+    const size_t per = (m + n_chunks - 1) / n_chunks;
+    for (int c = 0; c < n_chunks && st == ST_SUCCESS; c++) {
+      const size_t first = (size_t)c * per, cnt = first >= m ? 0 : (m - first < per ? m - first : per);
+      if (!cnt) break;
+      ctx->stream = (c & 1) ? ctx->side_stream : main_stream;
+      st = bary_eval_part(ctx, n_nodes, d_records, d_leaftab, h_scale, d_targets + first * ttda, cnt, ttda, d_values + first,
+                          d_leaf ? d_leaf + first : (int *)NULL, d_count, wrec, wsec[c & 1], m_cap, c & 1, false);
+    }
+    ctx->stream = main_stream;
+    HIP_OK(ctx, hipEventRecord(ctx->side_ev[3], ctx->side_stream));       /* join the odd chunks */
+    HIP_OK(ctx, hipStreamWaitEvent(main_stream, ctx->side_ev[3], 0));
+  }
+  if (st) return st;
   if (h_n_outside) {
     unsigned long long cnt = 0;
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_OK(ctx, hipMemcpy(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost));
+    HIP_OK(ctx, hipMemcpy(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
     *h_n_outside = (long long)cnt;
     if (cnt) return sinterp_fail(ctx, ST_EDOM, "bary_eval: target(s) outside the caging simplex", hipSuccess, __FILE__, __LINE__);

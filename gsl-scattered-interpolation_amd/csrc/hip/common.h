@@ -173,7 +173,7 @@ struct sinterp_sorted {
   unsigned long long *box;      /* bounding-box keys, box[2c] = min, box[2c+1] = max */
 };
 int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
-                         sinterp_sorted *out);
+                         sinterp_sorted *out, size_t m_cap, int slot, const unsigned long long *box_in);
 int sinterp_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf);
 /* vs holds {value, leaf-as-integer-bits} pairs (16 bytes per target; the vs region is sized for it) */
 int sinterp_unsort_packed(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf);

@@ -340,36 +340,52 @@ unsort_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ 
   }
 }
 
+/* m_cap >= m sizes the buffer section (two sections -- `slot` 0 / 1 -- so that two chunks of one batch can be in
+   flight on two streams); box_in != NULL: bounding-box keys to bin by (e.g. the data's box kept with the jump table)
+   instead of a pass over the targets -- points outside it land in the border cells, which only costs locality */
 int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
-                         sinterp_sorted *out)
+                         sinterp_sorted *out, size_t m_cap, int slot, const unsigned long long *box_in)
 {
   memset(out, 0, sizeof *out);
   if (m == 0) return ST_SUCCESS;
-  if (m > 0x7fffffffULL) return sinterp_fail(ctx, ST_EINVAL, "sort_reorder: more than 2^31 targets", hipSuccess, __FILE__, __LINE__);
+  if (m_cap < m) m_cap = m;
+  if (m_cap > 0x7fffffffULL) return sinterp_fail(ctx, ST_EINVAL, "sort_reorder: more than 2^31 targets", hipSuccess, __FILE__, __LINE__);
   double cells = (double)m / (double)(per_cell > 0 ? per_cell : 64);
   int g = (int)ceil(pow(cells < 1 ? 1.0 : cells, 1.0 / dim));
   const int gmax = dim == 1 ? (1 << 20) : (dim == 2 ? 1024 : 100);
   g = g < 1 ? 1 : (g > gmax ? gmax : g);
-  size_t ncell = 1;
+  size_t ncell = 1, ncell_cap = 1;
   for (int c = 0; c < dim; c++) ncell *= (size_t)g;
+  {
+    double cc = (double)m_cap / (double)(per_cell > 0 ? per_cell : 64);
+    int gc = (int)ceil(pow(cc < 1 ? 1.0 : cc, 1.0 / dim));
+    gc = gc < 1 ? 1 : (gc > gmax ? gmax : gc);
+    for (int c = 0; c < dim; c++) ncell_cap *= (size_t)gc;
+    if (ncell_cap < ncell) ncell_cap = ncell;
+  }
   /* layout: box | ys | vs | ls | cellid | slot | count(+1) ; every section 16-byte aligned */
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  const size_t o_ys = 64, o_vs = o_ys + up(m * dim * 8), o_ls = o_vs + up(m * 16), o_cell = o_ls + up(m * 4),
-               o_slot = o_cell + up(m * 4), o_cnt = o_slot + up(m * 4), bytes = o_cnt + up((ncell + 1) * 4 + (ncell / 1024 + 8) * 4);
+  const size_t o_ys = 64, o_vs = o_ys + up(m_cap * dim * 8), o_ls = o_vs + up(m_cap * 16), o_cell = o_ls + up(m_cap * 4),
+               o_slot = o_cell + up(m_cap * 4), o_cnt = o_slot + up(m_cap * 4),
+               bytes = (o_cnt + up((ncell_cap + 1) * 4 + (ncell_cap / 1024 + 8) * 4) + 255) & ~(size_t)255;
   void *buf = NULL;
-  int st = sinterp_sortbuf(ctx, bytes, &buf);
+  int st = sinterp_sortbuf(ctx, bytes * (slot >= 0 ? 2 : 1), &buf);
   if (st) return st;
-  char *b = (char *)buf;
+  char *b = (char *)buf + (slot > 0 ? bytes : 0);
   out->box = (unsigned long long *)b;
   out->ys = (double *)(b + o_ys); out->vs = (double *)(b + o_vs); out->ls = (int *)(b + o_ls);
   out->cellid = (unsigned *)(b + o_cell); out->slot = (unsigned *)(b + o_slot); out->offset = (unsigned *)(b + o_cnt);
-  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, out->box);
   HIP_OK(ctx, hipMemsetAsync(out->offset, 0, ncell * 4, ctx->stream));
   size_t blocks = (m + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, out->box);
+  const unsigned long long *box = box_in;
+  if (!box) {
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, out->box);
+    hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, out->box);
+    box = out->box;
+  } else out->box = (unsigned long long *)box_in;
   hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g,
-                     (const unsigned long long *)out->box, out->cellid, out->slot, out->offset);
+                     box, out->cellid, out->slot, out->offset);
   launch_cell_scan(ctx, out->offset, ncell, out->offset + ncell + 1);
   hipLaunchKernelGGL(cell_scatter_points_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim,
                      (const unsigned *)out->cellid, (const unsigned *)out->slot, (const unsigned *)out->offset, out->ys);
