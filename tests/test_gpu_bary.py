@@ -358,10 +358,10 @@ def test_large_batch_values_only_and_strided_targets(pkg, orc):
 
 
 def test_chunked_two_stream_pipeline_changes_no_bit(pkg, orc, monkeypatch):
-    """Round 3: a large batch is cut into four pieces that alternate between the context's stream and its side stream
-    (chunk i+1 is binned while chunk i walks).  A value depends on (records, target) only: chunked = one piece, bit for
-    bit, ragged sizes and NaN / outside targets included; GSL_SINTERP_BARY_CHUNK_MIN lowers the size at which the split
-    starts so that the path runs at test size (the C5 full-size test runs it at 10^7)."""
+    """Round 3 (opt-in, measured slower: DESIGN 6): with GSL_SINTERP_BARY_CHUNKS=1 a large batch is cut into four pieces
+    that alternate between the context's stream and its side stream (chunk i+1 is binned while chunk i walks).  A value
+    depends on (records, target) only: chunked = one piece, bit for bit, ragged sizes and NaN / outside targets
+    included; GSL_SINTERP_BARY_CHUNK_MIN lowers the size at which the split starts so that the path runs at test size."""
     n, m = 6000, 301_003
     x = orc.synth_centres(n, 2)
     f = orc.synth_response(x)
@@ -371,9 +371,8 @@ def test_chunked_two_stream_pipeline_changes_no_bit(pkg, orc, monkeypatch):
     t, o = build_pair(pkg, orc, x)
     d = t.device_alloc(0)
     assert d.set_response(f) == 0
-    monkeypatch.setenv("GSL_SINTERP_NO_BARY_CHUNKS", "1")
     st0, v0, l0 = d.eval_many(y)
-    monkeypatch.delenv("GSL_SINTERP_NO_BARY_CHUNKS")
+    monkeypatch.setenv("GSL_SINTERP_BARY_CHUNKS", "1")
     monkeypatch.setenv("GSL_SINTERP_BARY_CHUNK_MIN", "20000")
     for rep in range(2):                                       # twice: the sections are reused
         st1, v1, l1 = d.eval_many(y)

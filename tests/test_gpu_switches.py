@@ -23,7 +23,7 @@ CASES = [
     ("GSL_SINTERP_NO_DATAFLOW_TRSV", LINALG), ("GSL_SINTERP_NO_DATAFLOW_TRSV", RBF_INIT), ("GSL_SINTERP_TRSV_PAIRS", LINALG),
     ("GSL_SINTERP_LOOKAHEAD", LINALG),
     ("GSL_SINTERP_NO_SORT", RBF_SWEEP), ("GSL_SINTERP_NO_CULL", RBF_SWEEP), ("GSL_SINTERP_SERIAL_CELL_ORDER", RBF_SWEEP),
-    ("GSL_SINTERP_NO_SORT", BARY), ("GSL_SINTERP_NO_JUMP", BARY), ("GSL_SINTERP_NO_FASTDIV", BARY), ("GSL_SINTERP_NO_AFFINE_WALK", BARY), ("GSL_SINTERP_NO_SIDE_STREAM", BARY), ("GSL_SINTERP_NO_BARY_CHUNKS", BARY),
+    ("GSL_SINTERP_NO_SORT", BARY), ("GSL_SINTERP_NO_JUMP", BARY), ("GSL_SINTERP_NO_FASTDIV", BARY), ("GSL_SINTERP_NO_AFFINE_WALK", BARY), ("GSL_SINTERP_NO_SIDE_STREAM", BARY),
 ]
 
 
