@@ -407,7 +407,7 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
 /* rows below a 128-wide diagonal block: X = B L^-T in place.  64 rows per workgroup, wave w owns rows
    16w..16w+15 for all four 32-column steps, so the steps need no workgroup barrier. */
 __global__ void __launch_bounds__(256)
-chol_trsm128_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, const double *__restrict__ Dinvg)
+chol_trsm128_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, const double *__restrict__ Dinvg, size_t row_start)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *Bt = sm;                     /* [64][TR_LD] */
@@ -415,7 +415,7 @@ chol_trsm128_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, con
   double *Dvb = Lb + 6 * PBLK;         /* 4 inverted diagonal blocks */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const size_t row0 = j0 + PB + (size_t)blockIdx.x * 64;
+  const size_t row0 = row_start + (size_t)blockIdx.x * 64;    /* rows [row_start, n): the whole panel below the block, or a slice of it */
   {
     /* one round trip: every global load is issued before the first LDS store */
     double2 vb[16];
@@ -561,7 +561,7 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
     const size_t below = n - j0 - w;
     if (below)
       hipLaunchKernelGGL(chol_trsm128_kernel, dim3((unsigned)((below + 63) / 64)), dim3(256), lds_trsm, ctx->stream, A, lda, n, j0,
-                         (const double *)d_linv);
+                         (const double *)d_linv, j0 + PB);
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }
@@ -608,6 +608,171 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
   return join_pend(ctx, &mine);
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* Panel look-ahead (round 3).  In the plain recursion above every 128-wide panel costs a dependent chain
+       diag128 (27 us, ONE workgroup) -> trsm128 of all rows below -> the update that brings the next panel's
+       columns up to date (K = 128: 19 us, K = 256: 45 us, K = 512: 107 us, ... for the whole trailing block)
+   during which the chip is mostly idle (N = 16384: 9.9 ms of 32; N = 8192: 24 %, N = 4096: 32 % of the init).
+   The next diagonal block only needs ITS 128 x 128 tile updated, and the next row solve only the tile below it.
+   So the work is cut along that line and issued on two streams (edges of the captured graph):
+       main (the chain):  A-update = tile (p, p) -= L(p, K) L(p, K)^T  ->  diag128(p)  ->  trsm128 of the next 128 rows
+       side (the bulk):   trsm128 of the remaining rows  ->  B-update = the rows below of column block p+1
+                          -> C-update = the rest of the trailing block            (stream-K on all but LA_RESERVE CUs)
+   for every update with K <= LA_KMAX; larger updates (the 15 top nodes of the recursion at N = 16384) stay one launch on
+   the side stream with the chain waiting for it, as before.  Dependencies are hipEvents per panel:
+       E_diag[p]  main  L(p,p) and its inverted 32 x 32 blocks written          -> side trsm of panel p
+       E_crit[p]  main  tile (p+1, p) solved                                    -> side updates that read row block p+1
+       E_rest[p]  side  tiles (>= p+2, p) solved                                -> main A-updates that read row block >= p+2
+       E_B[p]     side  last update of tile (p+1, p)                            -> main trsm of that tile
+       E_dw[p]    side  last update of the diagonal tile (p, p) by the bulk     -> main A-update / diag128 of block p
+   The arithmetic per entry is the recursion's (same K ranges in the same order, the same kernels), only the tiling of
+   one update into launches differs: results agree with the plain driver to rounding of the stream-K split (both are
+   held to the oracle at 1e-12).  GSL_SINTERP_NO_PANEL_LA=1 selects the plain recursion. */
+#define LA_KMAX 512
+#define LA_RESERVE 8
+#define LA_MAX_PANELS 448
+
+struct LaCtx {
+  gsl_sinterp_hip_ctx *ctx;
+  double *A; size_t lda, n;
+  int *d_info; double *d_diag, *d_linv;
+  hipStream_t main, side;
+  hipEvent_t e_diag[LA_MAX_PANELS], e_crit[LA_MAX_PANELS], e_rest[LA_MAX_PANELS], e_b[LA_MAX_PANELS], e_dw[LA_MAX_PANELS];
+  hipEvent_t last_side;
+};
+
+static int la_wait(LaCtx &L, hipStream_t s, hipEvent_t ev)
+{
+  if (ev) HIP_OK(L.ctx, hipStreamWaitEvent(s, ev, 0));
+  return ST_SUCCESS;
+}
+
+static int la_record(LaCtx &L, hipStream_t s, hipEvent_t *out)
+{
+  hipEvent_t ev;
+  int st = la_event(L.ctx, &ev);
+  if (st) return st;
+  HIP_OK(L.ctx, hipEventRecord(ev, s));
+  *out = ev;
+  if (s == L.side) L.last_side = ev;
+  return ST_SUCCESS;
+}
+
+static int la_leaf(LaCtx &L, size_t j0)
+{
+  gsl_sinterp_hip_ctx *ctx = L.ctx;
+  const size_t p = j0 / PB, n = L.n;
+  int st;
+  const size_t lds_diag = (size_t)(14 * PBLK) * sizeof(double), lds_trsm = (size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double);
+  double *linv = L.d_linv + p * (4 * 1024);
+  if ((st = la_wait(L, L.main, L.e_dw[p]))) return st;                 /* the bulk's last word on tile (p, p) */
+  hipLaunchKernelGGL(chol_diag128_kernel, dim3(1), dim3(256), lds_diag, L.main, L.A, L.lda, j0, L.d_info, L.d_diag, linv);
+  if ((st = la_record(L, L.main, &L.e_diag[p]))) return st;
+  const size_t below = n - j0 - PB;
+  if (below == 0) { LAUNCH_CHECK(ctx); return ST_SUCCESS; }
+  const size_t crit = below < PB ? below : PB;
+  if ((st = la_wait(L, L.main, L.e_b[p]))) return st;
+  hipLaunchKernelGGL(chol_trsm128_kernel, dim3((unsigned)((crit + 63) / 64)), dim3(256), lds_trsm, L.main, L.A, L.lda, j0 + PB + crit, j0,
+                     (const double *)linv, j0 + PB);
+  if ((st = la_record(L, L.main, &L.e_crit[p]))) return st;
+  if (below > crit) {
+    if ((st = la_wait(L, L.side, L.e_diag[p]))) return st;
+    hipLaunchKernelGGL(chol_trsm128_kernel, dim3((unsigned)((below - crit + 63) / 64)), dim3(256), lds_trsm, L.side, L.A, L.lda, n, j0,
+                       (const double *)linv, j0 + PB + crit);
+    if ((st = la_record(L, L.side, &L.e_rest[p]))) return st;
+  }
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+/* C[r0.., r0 .. r0+w2) -= L[r0.., j0 .. j0+w1) L[r0 .. r0+w2, j0 .. j0+w1)^T, lower trapezoid */
+static int la_update(LaCtx &L, size_t j0, size_t w1, size_t r0, size_t w2)
+{
+  gsl_sinterp_hip_ctx *ctx = L.ctx;
+  double *A = L.A;
+  const size_t lda = L.lda, n = L.n, pr = r0 / PB, q0 = j0 / PB;
+  int st;
+  hipEvent_t ev;
+  if (w1 > LA_KMAX) {
+    /* a large update: one launch on the side stream, the chain waits for it (E_dw / E_b of the blocks it touches) */
+    if (pr >= 1 && (st = la_wait(L, L.side, L.e_crit[pr - 1]))) return st;
+    ctx->stream = L.side; ctx->sk_cap = 0; ctx->sk_alt = 0;
+    st = sinterp_gemm_minus(ctx, n - r0, w2, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
+    ctx->stream = L.main;
+    if (st) return st;
+    if ((st = la_record(L, L.side, &ev))) return st;
+    for (size_t q = pr; q < pr + w2 / PB && q < LA_MAX_PANELS; q++) { L.e_dw[q] = ev; L.e_b[q] = ev; }
+    return ST_SUCCESS;
+  }
+  /* main: the next diagonal block.  Reads L(pr, q0 .. pr-1): the last tile from the chain itself, the older ones from the bulk */
+  if ((st = la_wait(L, L.main, L.e_dw[pr]))) return st;
+  if (pr >= 2 && pr - 2 >= q0 && (st = la_wait(L, L.main, L.e_rest[pr - 2]))) return st;
+  ctx->stream = L.main; ctx->sk_cap = 0; ctx->sk_alt = 1;
+  st = sinterp_gemm_minus(ctx, PB, PB, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
+  ctx->sk_alt = 0;
+  if (st) return st;
+  /* side: everything below the block.  Reads row block pr (tile (pr, pr-1) comes from the chain) */
+  const size_t mb = n - r0 - PB;
+  if (mb > 0) {
+    if (pr >= 1 && (st = la_wait(L, L.side, L.e_crit[pr - 1]))) return st;
+    ctx->stream = L.side; ctx->sk_cap = ctx->sk_wgs > 2 * LA_RESERVE ? ctx->sk_wgs - LA_RESERVE : 0;
+    st = sinterp_gemm_minus(ctx, mb, PB, w1, A + (r0 + PB) * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + (r0 + PB) * lda + r0, lda, 0);
+    if (!st) st = la_record(L, L.side, &ev);
+    if (!st) L.e_b[pr] = ev;
+    if (!st && w2 > PB) {
+      st = sinterp_gemm_minus(ctx, mb, w2 - PB, w1, A + (r0 + PB) * lda + j0, lda, A + (r0 + PB) * lda + j0, lda, 0,
+                              A + (r0 + PB) * lda + r0 + PB, lda, 1);
+      if (!st) st = la_record(L, L.side, &ev);
+      if (!st) for (size_t q = pr + 1; q < pr + w2 / PB && q < LA_MAX_PANELS; q++) { L.e_dw[q] = ev; L.e_b[q] = ev; }
+    }
+    ctx->stream = L.main; ctx->sk_cap = 0;
+    if (st) return st;
+  }
+  return ST_SUCCESS;
+}
+
+static int la_panel(LaCtx &L, size_t j0, size_t w)
+{
+  if (w == PB) return la_leaf(L, j0);
+  const size_t w1 = chol_split(w);
+  int st = la_panel(L, j0, w1);
+  if (st) return st;
+  st = la_update(L, j0, w1, j0 + w1, w - w1);
+  if (st) return st;
+  return la_panel(L, j0 + w1, w - w1);
+}
+
+/* n = 128 T: the whole factorisation with panel look-ahead; ctx->stream is the (capturing) main stream */
+static int chol_lookahead(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, int *d_info, double *d_diag, double *d_linv)
+{
+  LaCtx *Lp = (LaCtx *)calloc(1, sizeof(LaCtx));          /* ~18 KB of event handles: not on the stack of a recursion */
+  if (!Lp) return sinterp_fail(ctx, ST_ENOMEM, "look-ahead state", hipSuccess, __FILE__, __LINE__);
+  struct Guard { LaCtx *p; ~Guard() { free(p); } } guard{Lp};
+  LaCtx &L = *Lp;
+  L.ctx = ctx; L.A = A; L.lda = lda; L.n = n; L.d_info = d_info; L.d_diag = d_diag; L.d_linv = d_linv;
+  if (!ctx->la_stream[0]) HIP_OK(ctx, hipStreamCreateWithFlags(&ctx->la_stream[0], hipStreamNonBlocking));
+  L.main = ctx->stream; L.side = ctx->la_stream[0];
+  { int ast = sinterp_func_lds(ctx, (const void *)chol_diag128_kernel, (int)((size_t)(14 * PBLK) * sizeof(double))); if (ast) return ast; }
+  { int ast = sinterp_func_lds(ctx, (const void *)chol_trsm128_kernel, (int)((size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double))); if (ast) return ast; }
+  /* fork: the side stream starts behind whatever the main stream has done so far (and joins the capture) */
+  hipEvent_t fork;
+  int st = la_event(ctx, &fork);
+  if (st) return st;
+  HIP_OK(ctx, hipEventRecord(fork, L.main));
+  HIP_OK(ctx, hipStreamWaitEvent(L.side, fork, 0));
+  st = la_panel(L, 0, n);
+  ctx->stream = L.main; ctx->sk_cap = 0; ctx->sk_alt = 0;
+  /* join */
+  hipEvent_t join;
+  int st2 = la_event(ctx, &join);
+  if (!st2) {
+    if (hipEventRecord(join, L.side) != hipSuccess || hipStreamWaitEvent(L.main, join, 0) != hipSuccess)
+      st2 = sinterp_fail(ctx, ST_EFAILED, "look-ahead join", hipSuccess, __FILE__, __LINE__);
+  }
+  return st ? st : st2;
+}
+
 __global__ void chol_zero_info_kernel(int *info) { *info = 0; }
 
 /* symmetric_input: both triangles of d_a hold the matrix (the RBF fill writes it that way), so the
@@ -624,7 +789,10 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
   int *d_info = (int *)ctx->d_scratch + 8;
   const size_t nblk = (n + CB - 1) / CB;
   void *d_diag = NULL;
-  int st = sinterp_workspace(ctx, (nblk * CB * CB + PB * PB) * sizeof(double), &d_diag);   /* diagonal blocks + one L^-1 */
+  /* diagonal blocks + the inverted 32 x 32 blocks of EVERY 128-wide panel (look-ahead: a panel's row solve on the side
+     stream still reads them while the chain factors the next panel) */
+  const size_t n_pan = (n + PB - 1) / PB;
+  int st = sinterp_workspace(ctx, (nblk * CB * CB + (n_pan + 1) * (4 * 1024)) * sizeof(double), &d_diag);
   if (st) return st;
   st = sinterp_streamk_prepare(ctx);
   if (st) return st;
@@ -643,7 +811,12 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
     const unsigned nt = (unsigned)((n + 31) / 32);
     if (!symmetric_input) hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
     ctx->la_events_used = 0;
-    st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag, 0, NULL);
+    static const bool no_la = getenv("GSL_SINTERP_NO_PANEL_LA") && getenv("GSL_SINTERP_NO_PANEL_LA")[0] == '1';
+    static const bool no_p128 = getenv("GSL_SINTERP_NO_PANEL128") && getenv("GSL_SINTERP_NO_PANEL128")[0] == '1';
+    const bool la = !no_la && !no_p128 && !ctx->use_lookahead && ctx->sk_wgs > 2 * LA_RESERVE && n % PB == 0 && n >= 2 * PB && n_pan <= LA_MAX_PANELS &&
+                    (lda & 1) == 0 && ((((uintptr_t)d_a) & 15) == 0);
+    if (la) st = chol_lookahead(ctx, d_a, lda, n, d_info, (double *)d_diag, (double *)d_diag + nblk * (CB * CB));
+    else st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag, 0, NULL);
     hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
                        (const double *)d_diag);
     int st2 = sinterp_capture_end(ctx, saved, 0, n, lda, d_a, gkey);

@@ -52,6 +52,12 @@ struct gsl_sinterp_hip_ctx {
   unsigned *d_sk_flags;
   unsigned *d_sk_tiles;     /* XCD super-tile order of the current large update (tile id -> tm, tn) */
   int sk_wgs;               /* persistent workgroups = CUs of the device; 0 = not prepared */
+  /* panel look-ahead of the Cholesky driver (chol.hip): two stream-K launches may be in flight at once -- the bulk
+     update on the side stream, capped at sk_cap workgroups so that the chain's kernels find free CUs, and the small
+     update of the next diagonal block on the main stream, which uses its own partial-tile / flag buffers (sk_alt) */
+  int sk_cap, sk_alt;
+  double *d_sk_partial2;
+  unsigned *d_sk_flags2;
   /* dataflow sweeps (chol.hip): [0] = epoch of the last completed sweep, [1 + J] = epoch in which
      block J was last published.  Never reset (no memset node in the captured graphs): a sweep
      publishes with epoch + 1 and its last block advances the epoch. */

@@ -199,6 +199,7 @@ gemm_minus_kernel(GemmArgs g)
    k = lane>>4) ds_read_b64 stays bank-conflict free. */
 #define DM_STAGES 3
 #define SK_TILE_TABLE_ENTRIES 262144u   /* tile-order table of the stream-K kernel (1 MiB) */
+#define SK_ALT_WGS 8                    /* workgroups of a launch on the alternate stream-K buffers (look-ahead chain) */
 
 __device__ __forceinline__ void dma16(const double *gsrc, double *ldst)
 {
@@ -396,8 +397,8 @@ __device__ __forceinline__ void decode_tile(const GemmArgs &g, unsigned tile, in
    step is then 16 k-rows of BN doubles, each row one linear 1-KiB DMA wave-instruction (BN = 128), rows pitched
    BN + 16 doubles apart so that the (k = lane>>4, n = lane&15) fragment read -- 16 consecutive doubles per k-row,
    k-rows 32 banks apart -- is conflict-free; no swizzle needed. */
-template <int BM, int BN, int WM, int WN, int SS = 1, int ST = DM_STAGES, bool PIPE = false, bool BKN = false>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 1)
+template <int BM, int BN, int WM, int WN, int SS = 1, int ST = DM_STAGES, bool PIPE = false, bool BKN = false, int WGPC = 1>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, WGPC * (BM / WM) * (BN / WN) / 4 > 0 ? WGPC * (BM / WM) * (BN / WN) / 4 : 1)
 gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 {
   static_assert(ST == 3 || ST == 2, "ring depth");
@@ -757,9 +758,12 @@ int sinterp_streamk_prepare(gsl_sinterp_hip_ctx *ctx)
   HIP_OK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
   if (cus <= 0) return ST_SUCCESS;
   HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_partial, (size_t)cus * 256 * GT_BN * sizeof(double)));
-  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_flags, (size_t)cus * sizeof(unsigned)));
+  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_flags, (size_t)cus * 2 * sizeof(unsigned)));   /* 2 x: the two-workgroups-per-CU variant */
   HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_tiles, SK_TILE_TABLE_ENTRIES * sizeof(unsigned)));
-  HIP_OK(ctx, hipMemset(ctx->d_sk_flags, 0, (size_t)cus * sizeof(unsigned)));
+  HIP_OK(ctx, hipMemset(ctx->d_sk_flags, 0, (size_t)cus * 2 * sizeof(unsigned)));
+  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_partial2, (size_t)SK_ALT_WGS * 256 * GT_BN * sizeof(double)));
+  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_flags2, (size_t)SK_ALT_WGS * sizeof(unsigned)));
+  HIP_OK(ctx, hipMemset(ctx->d_sk_flags2, 0, (size_t)SK_ALT_WGS * sizeof(unsigned)));
   HIP_OK(ctx, hipDeviceSynchronize());
   ctx->sk_wgs = cus;
   return ST_SUCCESS;
@@ -876,7 +880,8 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       /* stream-K: G persistent workgroups share the (tile, K-step) space evenly */
       StreamK x;
       x.steps = (unsigned)(k / GT_BK);                   /* groups per tile; rescaled below for the grouped 64x64 variant */
-      x.partial = ctx->d_sk_partial; x.flags = ctx->d_sk_flags;
+      x.partial = ctx->sk_alt ? ctx->d_sk_partial2 : ctx->d_sk_partial;
+      x.flags = ctx->sk_alt ? ctx->d_sk_flags2 : ctx->d_sk_flags;
       GemmArgs h = g;
       unsigned tiles = grid;
       int cfg = 1;                                       /* 0: 256x128, 1: 128x128, 2: 64x64 */
@@ -904,7 +909,8 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       /* developer override (tools/gemm_cfg_sweep.py): force the tile configuration where the shape allows it */
       if (getenv("GSL_SINTERP_GEMM_CFG")) {
         const int want_cfg = atoi(getenv("GSL_SINTERP_GEMM_CFG"));
-        if (want_cfg == 1 || (want_cfg == 2 && m % 64 == 0 && n % 64 == 0)) {
+        if (want_cfg == 3 || want_cfg == 4) { cfg = want_cfg; h = g; tiles = grid; }
+        else if (want_cfg == 1 || (want_cfg == 2 && m % 64 == 0 && n % 64 == 0)) {
           cfg = want_cfg; h = g; tiles = grid;
           if (want_cfg == 2) {
             h.tiles_m = (int)(m / 64); h.tiles_n = (int)(n / 64);
@@ -920,7 +926,10 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       unsigned long long total64 = (unsigned long long)tiles * x.steps;
       unsigned long long want = total64 / (grouped ? 4 : 16);   /* >= 16 K-steps (of 16) per workgroup ... */
       if (want < tiles) want = tiles;                     /* ... but never fewer workgroups than tiles */
-      if (want > (unsigned long long)ctx->sk_wgs) want = (unsigned long long)ctx->sk_wgs;
+      unsigned long long wg_cap = (unsigned long long)ctx->sk_wgs * ((cfg == 3 || cfg == 4) ? 2 : 1);
+      if (ctx->sk_cap > 0 && (unsigned long long)ctx->sk_cap < wg_cap) wg_cap = (unsigned long long)ctx->sk_cap;
+      if (ctx->sk_alt && wg_cap > SK_ALT_WGS) wg_cap = SK_ALT_WGS;
+      if (want > wg_cap) want = wg_cap;
       const unsigned G = (unsigned)(want ? want : 1);
       /* many tiles: all but the last full round (and the remainder) as whole tiles */
       static const bool no_hybrid = getenv("GSL_SINTERP_NO_HYBRID_SK") && getenv("GSL_SINTERP_NO_HYBRID_SK")[0] == '1';
@@ -939,7 +948,20 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       if (total64 < 0x7fffffffull) {
       x.total = (unsigned)total64; x.base = x.total / G; x.rem = x.total % G;
       static const bool no_pipe = getenv("GSL_SINTERP_NO_GEMM_PIPE") && getenv("GSL_SINTERP_NO_GEMM_PIPE")[0] == '1';
-      if (cfg == 0 && !no_pipe) {
+      if (cfg == 3) {
+        /* EXPERIMENT (GSL_SINTERP_GEMM_CFG=3): 128 x 128 tiles, TWO workgroups per CU on a two-deep ring (64 KiB each):
+           the waves of one workgroup wait at their barrier while the other workgroup's waves feed the matrix pipe */
+        const size_t lds = (size_t)2 * (128 + 128) * GT_BK * sizeof(double);
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<128, 128, 64, 64, 1, 2, false, false, 2>, (int)lds); if (ast) return ast; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<128, 128, 64, 64, 1, 2, false, false, 2>), dim3(G), dim3(256), lds, ctx->stream, h, x);
+      } else if (cfg == 4) {
+        /* EXPERIMENT (GSL_SINTERP_GEMM_CFG=4): the same with two 16-wide sub-steps per barrier pair (128 KiB for two workgroups) */
+        const size_t lds = (size_t)2 * 2 * (128 + 128) * GT_BK * sizeof(double);
+        x.steps = (unsigned)(k / (2 * GT_BK));
+        { unsigned long long t64 = (unsigned long long)(tiles - x.dp_rounds * G) * x.steps; x.total = (unsigned)t64; x.base = x.total / G; x.rem = x.total % G; }
+        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<128, 128, 64, 64, 2, 2, false, false, 2>, (int)lds); if (ast) return ast; }
+        hipLaunchKernelGGL((gemm_minus_streamk_kernel<128, 128, 64, 64, 2, 2, false, false, 2>), dim3(G), dim3(256), lds, ctx->stream, h, x);
+      } else if (cfg == 0 && !no_pipe) {
         const size_t lds = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);
         { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<256, 128, 64, 64, 1, 3, true>, (int)lds); if (ast) return ast; }
         hipLaunchKernelGGL((gemm_minus_streamk_kernel<256, 128, 64, 64, 1, 3, true>), dim3(G), dim3(512), lds, ctx->stream, h, x);

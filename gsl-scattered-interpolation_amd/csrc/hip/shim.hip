@@ -84,6 +84,8 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->d_sk_partial) (void)hipFree(ctx->d_sk_partial);
   if (ctx->d_sk_flags) (void)hipFree(ctx->d_sk_flags);
+  if (ctx->d_sk_partial2) (void)hipFree(ctx->d_sk_partial2);
+  if (ctx->d_sk_flags2) (void)hipFree(ctx->d_sk_flags2);
   if (ctx->d_sk_tiles) (void)hipFree(ctx->d_sk_tiles);
   if (ctx->d_tf) (void)hipFree(ctx->d_tf);
   if (ctx->d_xq) (void)hipFree(ctx->d_xq);
