@@ -628,7 +628,15 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
        E_dw[p]    side  last update of the diagonal tile (p, p) by the bulk     -> main A-update / diag128 of block p
    The arithmetic per entry is the recursion's (same K ranges in the same order, the same kernels), only the tiling of
    one update into launches differs: results agree with the plain driver to rounding of the stream-K split (both are
-   held to the oracle at 1e-12).  GSL_SINTERP_NO_PANEL_LA=1 selects the plain recursion. */
+   held to the oracle at 1e-12; tests/test_gpu_switches.py runs the linalg / RBF parity tests with it).
+   NEGATIVE RESULT, opt-in (GSL_SINTERP_PANEL_LA=1).  Measured on MI355X (bench.py, init phase): N = 4096 3.12 vs 2.76 ms,
+   N = 8192 7.70 vs 7.23 ms, N = 16384 32.85 vs 32.33 ms -- slower everywhere.  The kernel trace
+   (profiles/r03_chol_panel_lookahead_trace_N4096.txt) shows why: the two queues do overlap as planned (the bulk trsm
+   and B-update run beside the chain's trsm / A-update / diag128), but every dependency that crosses the queues costs
+   5-9 us of signal latency inside the replayed graph against ~1.5 us between dependent kernels of one stream, and
+   the chain crosses twice per panel; diag128-to-diag128 is 72 us with the look-ahead against 62 us (K = 128 nodes)
+   and 84 us (K = 256 nodes) without.  Overlapping the chain needs in-kernel hand-offs (a persistent panel kernel),
+   not streams. */
 #define LA_KMAX 512
 #define LA_RESERVE 8
 #define LA_MAX_PANELS 448
@@ -811,7 +819,8 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
     const unsigned nt = (unsigned)((n + 31) / 32);
     if (!symmetric_input) hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
     ctx->la_events_used = 0;
-    static const bool no_la = getenv("GSL_SINTERP_NO_PANEL_LA") && getenv("GSL_SINTERP_NO_PANEL_LA")[0] == '1';
+    /* opt-in: measured slower than the plain recursion (see the comment above chol_lookahead) */
+    static const bool no_la = !(getenv("GSL_SINTERP_PANEL_LA") && getenv("GSL_SINTERP_PANEL_LA")[0] == '1');
     static const bool no_p128 = getenv("GSL_SINTERP_NO_PANEL128") && getenv("GSL_SINTERP_NO_PANEL128")[0] == '1';
     const bool la = !no_la && !no_p128 && !ctx->use_lookahead && ctx->sk_wgs > 2 * LA_RESERVE && n % PB == 0 && n >= 2 * PB && n_pan <= LA_MAX_PANELS &&
                     (lda & 1) == 0 && ((((uintptr_t)d_a) & 15) == 0);
