@@ -130,6 +130,9 @@ SIGNATURES = {
     "gsl_sinterp_hip_lu_refine": (_i, [_vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "gsl_sinterp_hip_pcholesky_decomp": (_i, [_vp, _sz, _vp, _sz, _vp]),
     "gsl_sinterp_hip_pcholesky_svx": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "gsl_sinterp_hip_pcholesky_decomp2": (_i, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "gsl_sinterp_hip_pcholesky_svx2": (_i, [_vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "gsl_sinterp_hip_pcholesky_rcond": (_i, [_vp, _sz, _vp, _sz, _vp, _pd]),
     "gsl_sinterp_hip_rbf_solve_ex": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _i, _pd, _pi]),
     "gsl_sinterp_hip_rbf_eval": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp]),
     "gsl_sinterp_hip_rbf_eval_model": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp, C.c_uint64]),
@@ -422,6 +425,17 @@ class HipContext:
 
     def pcholesky_svx(self, n, d_ldlt, lda, d_perm, d_x):
         check(lib().gsl_sinterp_hip_pcholesky_svx(self._h, n, d_ldlt, lda, d_perm, d_x), self._h)
+
+    def pcholesky_decomp2(self, n, d_a, lda, d_perm, d_s):
+        check(lib().gsl_sinterp_hip_pcholesky_decomp2(self._h, n, d_a, lda, d_perm, d_s), self._h)
+
+    def pcholesky_svx2(self, n, d_ldlt, lda, d_perm, d_s, d_x):
+        check(lib().gsl_sinterp_hip_pcholesky_svx2(self._h, n, d_ldlt, lda, d_perm, d_s, d_x), self._h)
+
+    def pcholesky_rcond(self, n, d_ldlt, lda, d_perm):
+        r = C.c_double(0)
+        check(lib().gsl_sinterp_hip_pcholesky_rcond(self._h, n, d_ldlt, lda, d_perm, C.byref(r)), self._h)
+        return r.value
 
     def rbf_solve_ex(self, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, solver, want_rcond=False):
         route, rc = C.c_int(0), C.c_double(0)

@@ -107,35 +107,20 @@ chol_norm1_kernel(const double *__restrict__ llt, size_t lda, size_t n, unsigned
 
 static double host_asum(const double *x, size_t n) { double r = 0.0; for (size_t i = 0; i < n; i++) r += fabs(x[i]); return r; }
 
-extern "C" int gsl_sinterp_hip_cholesky_rcond(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda, double *h_rcond)
+/* condest.c:95-188 (Hager / Higham estimate of |A^-1|_1, at most 5 iterations) with x := A^-1 x done on the device by
+   `solve(d_v)`; the O(N) vector work of the estimator (signs, argmax, 1-norms) stays on the host: at most 8 solves of
+   one vector each */
+template <class Solve>
+static int invnorm1_device(gsl_sinterp_hip_ctx *ctx, size_t n, Solve solve, double *gamma_out)
 {
-  REQUIRE(ctx, ctx != NULL && h_rcond != NULL, ST_EFAULT);
-  HIP_OK(ctx, hipSetDevice(ctx->device));
-  REQUIRE(ctx, lda >= n, ST_EINVAL);
-  *h_rcond = 0.0;
-  if (n == 0) return ST_SUCCESS;
-  REQUIRE(ctx, d_llt != NULL, ST_EFAULT);
-  unsigned long long *d_norm = (unsigned long long *)((char *)ctx->d_scratch + 256);
-  HIP_OK(ctx, hipMemsetAsync(d_norm, 0, sizeof *d_norm, ctx->stream));
-  hipLaunchKernelGGL(chol_norm1_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_llt, lda, n, d_norm);
-  LAUNCH_CHECK(ctx);
-  unsigned long long bits = 0;
-  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_OK(ctx, hipMemcpy(&bits, d_norm, sizeof bits, hipMemcpyDeviceToHost));
-  double anorm;
-  memcpy(&anorm, &bits, sizeof anorm);
-  if (anorm == 0.0) return ST_SUCCESS;                  /* cholesky.c:523-524 */
-
-  /* condest.c:95-188 with x := A^-1 x = L^-T L^-1 x done by the blocked sweeps; the O(N) vector work of the
-     estimator (signs, argmax, 1-norms) stays on the host: at most 8 solves of one vector each */
   double *d_v = NULL;
   double *x = (double *)malloc(3 * n * sizeof(double));
-  if (!x) return sinterp_fail(ctx, ST_ENOMEM, "cholesky_rcond: host workspace", hipSuccess, __FILE__, __LINE__);
+  if (!x) return sinterp_fail(ctx, ST_ENOMEM, "rcond: host workspace", hipSuccess, __FILE__, __LINE__);
   double *v = x + n, *xi = x + 2 * n;
   int st = gsl_sinterp_hip_malloc(ctx, (void **)&d_v, n * sizeof(double));
   auto ainv = [&](double *h) -> int {
     int s = gsl_sinterp_hip_h2d(ctx, d_v, h, n * sizeof(double));
-    if (!s) s = gsl_sinterp_hip_cholesky_svx(ctx, n, d_llt, lda, d_v);
+    if (!s) s = solve(d_v);
     if (!s) s = gsl_sinterp_hip_d2h(ctx, h, d_v, n * sizeof(double));
     return s;
   };
@@ -175,11 +160,36 @@ extern "C" int gsl_sinterp_hip_cholesky_rcond(gsl_sinterp_hip_ctx *ctx, size_t n
     if (!st) {
       temp = 2.0 * host_asum(x, n) / (3.0 * (double)n);
       if (temp > gamma) gamma = temp;
-      if (gamma != 0.0) *h_rcond = (1.0 / anorm) / gamma;
     }
   }
   gsl_sinterp_hip_free(ctx, d_v);
   free(x);
+  *gamma_out = gamma;
+  return st;
+}
+
+extern "C" int gsl_sinterp_hip_cholesky_rcond(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_llt, size_t lda, double *h_rcond)
+{
+  REQUIRE(ctx, ctx != NULL && h_rcond != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  REQUIRE(ctx, lda >= n, ST_EINVAL);
+  *h_rcond = 0.0;
+  if (n == 0) return ST_SUCCESS;
+  REQUIRE(ctx, d_llt != NULL, ST_EFAULT);
+  unsigned long long *d_norm = (unsigned long long *)((char *)ctx->d_scratch + 256);
+  HIP_OK(ctx, hipMemsetAsync(d_norm, 0, sizeof *d_norm, ctx->stream));
+  hipLaunchKernelGGL(chol_norm1_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_llt, lda, n, d_norm);
+  LAUNCH_CHECK(ctx);
+  unsigned long long bits = 0;
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(&bits, d_norm, sizeof bits, hipMemcpyDeviceToHost));
+  double anorm;
+  memcpy(&anorm, &bits, sizeof anorm);
+  if (anorm == 0.0) return ST_SUCCESS;                  /* cholesky.c:523-524 */
+
+  double gamma = 0.0;
+  int st = invnorm1_device(ctx, n, [&](double *d_v) -> int { return gsl_sinterp_hip_cholesky_svx(ctx, n, d_llt, lda, d_v); }, &gamma);
+  if (!st && gamma != 0.0) *h_rcond = (1.0 / anorm) / gamma;
   return st;
 }
 
@@ -307,7 +317,15 @@ tricpy_l2u_kernel(double *__restrict__ a, size_t lda, size_t n)
   if (j < i && i < n) a[j * lda + i] = a[i * lda + j];
 }
 
+static int pcholesky_decomp_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *d_perm, bool copy_uplo);
+
 extern "C" int gsl_sinterp_hip_pcholesky_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *d_perm)
+{
+  return pcholesky_decomp_impl(ctx, n, d_a, lda, d_perm, true);
+}
+
+/* pcholesky_decomp(copy_uplo, A, p) of linalg/pcholesky.c:71-154 */
+static int pcholesky_decomp_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *d_perm, bool copy_uplo)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   HIP_OK(ctx, hipSetDevice(ctx->device));
@@ -319,7 +337,7 @@ extern "C" int gsl_sinterp_hip_pcholesky_decomp(gsl_sinterp_hip_ctx *ctx, size_t
   if (st) return st;
   double *v = (double *)buf, *alphainv = v + n;
   const unsigned nb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(tricpy_l2u_kernel, dim3(nb, (unsigned)n), dim3(256), 0, ctx->stream, d_a, lda, n);   /* pcholesky.c:91-95 */
+  if (copy_uplo) hipLaunchKernelGGL(tricpy_l2u_kernel, dim3(nb, (unsigned)n), dim3(256), 0, ctx->stream, d_a, lda, n);   /* pcholesky.c:91-95 */
   hipLaunchKernelGGL(pchol_init_perm_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_perm, n);
   for (size_t k = 0; k < n; k++) {
     hipLaunchKernelGGL(pchol_pivot_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_a, lda, n, k, d_perm, v, alphainv);
@@ -373,4 +391,105 @@ extern "C" int gsl_sinterp_hip_pcholesky_svx(gsl_sinterp_hip_ctx *ctx, size_t n,
   hipLaunchKernelGGL(permute_scatter_d_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)t0, d_perm, d_x, n);  /* x = P^T z */
   LAUNCH_CHECK(ctx);
   return ST_SUCCESS;
+}
+
+
+/* ------------------------------------------------------------------------ */
+/* gsl_linalg_pcholesky_decomp2 / _svx2 / _rcond (linalg/pcholesky.c:231-353, 472-580) */
+extern "C" int gsl_sinterp_hip_pcholesky_decomp2(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *d_perm, double *d_s)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  REQUIRE(ctx, lda >= n && n <= 65535, ST_EINVAL);
+  REQUIRE(ctx, n == 0 || (d_a && d_perm && d_s), ST_EFAULT);
+  if (n == 0) return ST_SUCCESS;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  /* the UNSCALED matrix goes to the strict upper triangle first (:251-252), then the lower triangle is scaled (:254-262) */
+  hipLaunchKernelGGL(tricpy_l2u_kernel, dim3(nb, (unsigned)n), dim3(256), 0, ctx->stream, d_a, lda, n);
+  hipLaunchKernelGGL(chol_scale_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_a, lda, n, d_s);
+  hipLaunchKernelGGL(chol_scale_apply_kernel, dim3(nb, (unsigned)n), dim3(256), 0, ctx->stream, d_a, lda, n, (const double *)d_s);
+  LAUNCH_CHECK(ctx);
+  return pcholesky_decomp_impl(ctx, n, d_a, lda, d_perm, false);
+}
+
+extern "C" int gsl_sinterp_hip_pcholesky_svx2(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_ldlt, size_t lda, const int *d_perm,
+                                              const double *d_s, double *d_x)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  REQUIRE(ctx, lda >= n, ST_EINVAL);
+  REQUIRE(ctx, n == 0 || (d_ldlt && d_perm && d_s && d_x), ST_EFAULT);
+  if (n == 0) return ST_SUCCESS;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(vec_mul_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_x, d_s, n);      /* x := S b */
+  LAUNCH_CHECK(ctx);
+  int st = gsl_sinterp_hip_pcholesky_svx(ctx, n, d_ldlt, lda, d_perm, d_x);
+  if (st) return st;
+  hipLaunchKernelGGL(vec_mul_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_x, d_s, n);      /* x = S x~ */
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+/* A_jj of the pivoted matrix rebuilt from L D L^T: D_j + sum_{i<j} D_i L_ji^2 (pcholesky.c:536-551); one workgroup per j */
+__global__ void __launch_bounds__(256)
+pchol_diag_kernel(const double *__restrict__ ldlt, size_t lda, size_t n, double *__restrict__ out)
+{
+  __shared__ double s_red[4];
+  const size_t j = blockIdx.x;
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < j; i += 256) { const double l = ldlt[j * lda + i]; acc += ldlt[i * lda + i] * l * l; }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[j] = ldlt[j * lda + j] + ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+}
+
+/* column j of |A|: the strict upper triangle holds the original matrix, the diagonal comes from diag[] */
+__global__ void __launch_bounds__(256)
+pchol_norm1_kernel(const double *__restrict__ ldlt, size_t lda, size_t n, const double *__restrict__ diag, unsigned long long *__restrict__ out)
+{
+  __shared__ double s_red[4];
+  const size_t j = blockIdx.x;
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < j; i += 256) acc += fabs(ldlt[i * lda + j]);
+  for (size_t c = j + 1 + threadIdx.x; c < n; c += 256) acc += fabs(ldlt[j * lda + c]);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + fabs(diag[j]);
+    atomicMax(out, (unsigned long long)__double_as_longlong(t));
+  }
+}
+
+extern "C" int gsl_sinterp_hip_pcholesky_rcond(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_ldlt, size_t lda, const int *d_perm,
+                                               double *h_rcond)
+{
+  REQUIRE(ctx, ctx != NULL && h_rcond != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  REQUIRE(ctx, lda >= n, ST_EINVAL);
+  *h_rcond = 0.0;
+  if (n == 0) return ST_SUCCESS;
+  REQUIRE(ctx, d_ldlt != NULL && d_perm != NULL, ST_EFAULT);
+  void *buf = NULL;
+  int st = sinterp_aux(ctx, 2 * n * sizeof(double), &buf);
+  if (st) return st;
+  double *dp = (double *)buf, *diag = dp + n;
+  unsigned long long *d_norm = (unsigned long long *)((char *)ctx->d_scratch + 256);
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  HIP_OK(ctx, hipMemsetAsync(d_norm, 0, sizeof *d_norm, ctx->stream));
+  hipLaunchKernelGGL(pchol_diag_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_ldlt, lda, n, dp);
+  hipLaunchKernelGGL(permute_scatter_d_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const double *)dp, d_perm, diag, n);   /* permute_vector_inverse */
+  hipLaunchKernelGGL(pchol_norm1_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_ldlt, lda, n, (const double *)diag, d_norm);
+  LAUNCH_CHECK(ctx);
+  unsigned long long bits = 0;
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(&bits, d_norm, sizeof bits, hipMemcpyDeviceToHost));
+  double anorm;
+  memcpy(&anorm, &bits, sizeof anorm);
+  if (anorm == 0.0) return ST_SUCCESS;                  /* pcholesky.c:497-498 */
+  double gamma = 0.0;
+  st = invnorm1_device(ctx, n, [&](double *d_v) -> int { return gsl_sinterp_hip_pcholesky_svx(ctx, n, d_ldlt, lda, d_perm, d_v); }, &gamma);
+  if (!st && gamma != 0.0) *h_rcond = (1.0 / anorm) / gamma;
+  return st;
 }

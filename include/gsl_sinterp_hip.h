@@ -170,6 +170,15 @@ int gsl_sinterp_hip_lu_refine(gsl_sinterp_hip_ctx *ctx, size_t n, const double *
 int gsl_sinterp_hip_pcholesky_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *d_perm);
 int gsl_sinterp_hip_pcholesky_svx(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_ldlt, size_t lda,
                                   const int *d_perm, double *d_x);
+/* gsl_linalg_pcholesky_decomp2 / _svx2 (linalg/pcholesky.c:231-353): the matrix is kept UNSCALED in the strict upper
+   triangle, S_i = 1/sqrt(A_ii) -> d_s, pivoted LDL^T of diag(S) A diag(S); svx2: x *= S, svx, x *= S.
+   gsl_linalg_pcholesky_rcond (:472-580): reciprocal 1-norm condition number of the matrix in the upper triangle (its
+   diagonal rebuilt from L D L^T), for the UNSCALED decomposition like the reference's own test (test_cholesky.c:675-687). */
+int gsl_sinterp_hip_pcholesky_decomp2(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *d_perm, double *d_s);
+int gsl_sinterp_hip_pcholesky_svx2(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_ldlt, size_t lda, const int *d_perm,
+                                   const double *d_s, double *d_x);
+int gsl_sinterp_hip_pcholesky_rcond(gsl_sinterp_hip_ctx *ctx, size_t n, const double *d_ldlt, size_t lda, const int *d_perm,
+                                    double *h_rcond);
 
 int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x,
                              size_t n, int dim, size_t xtda, const double *d_w,

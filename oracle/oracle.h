@@ -73,6 +73,9 @@ int oracle_lu_refine(size_t n, const double *a, size_t lda, const double *lu, si
                      const double *b, double *x, double *work);                                  /* linalg/lu.c:204 */
 int oracle_pcholesky_decomp(size_t n, double *a, size_t lda, size_t *perm);                     /* linalg/pcholesky.c:71 */
 int oracle_pcholesky_svx(size_t n, const double *ldlt, size_t lda, const size_t *perm, double *x); /* linalg/pcholesky.c:190 */
+int oracle_pcholesky_decomp2(size_t n, double *a, size_t lda, size_t *perm, double *s);            /* linalg/pcholesky.c:231 */
+int oracle_pcholesky_svx2(size_t n, const double *ldlt, size_t lda, const size_t *perm, const double *s, double *x); /* :314 */
+int oracle_pcholesky_rcond(size_t n, const double *ldlt, size_t lda, const size_t *perm, double *rcond, double *work); /* :472; work 3n */
 
 /* ======================= simplex tree (oracle_simplex.c) ============= */
 #define ORACLE_TREE_DEFAULT 0

@@ -183,28 +183,24 @@ static double cholesky_norm1(size_t n, const double *llt, size_t lda, double *wo
 
 static double asum(size_t n, const double *x) { double r = 0.0; for (size_t i = 0; i < n; i++) r += fabs(x[i]); return r; }
 
-/* linalg/condest.c:95-188 (Hager / Higham estimator, at most 5 iterations), A^-1 = L^-T L^-1 (cholesky.c:584-604) */
-int oracle_cholesky_rcond(size_t n, const double *llt, size_t lda, double *rcond, double *work)
+/* linalg/condest.c:95-188 (Hager / Higham estimator of |A^-1|_1, at most 5 iterations); solve(ctx, x): x := A^-1 x */
+static double invnorm1(size_t n, void (*solve)(void *, double *), void *ctx, double *work)
 {
-  *rcond = 0.0;
-  if (n == 0) return ORACLE_SUCCESS;
-  const double anorm = cholesky_norm1(n, llt, lda, work);
-  if (anorm == 0.0) return ORACLE_SUCCESS;
   double *x = work, *v = work + n, *xi = work + 2 * n;
   for (size_t i = 0; i < n; i++) x[i] = 1.0 / (double)n;
   for (size_t i = 0; i < n; i++) v[i] = x[i];
-  oracle_cholesky_svx(n, llt, lda, v);
+  solve(ctx, v);
   double gamma = asum(n, v), gamma_old;
   for (size_t i = 0; i < n; i++) xi[i] = v[i] >= 0.0 ? 1 : -1;
   for (size_t i = 0; i < n; i++) x[i] = xi[i];
-  oracle_cholesky_svx(n, llt, lda, x);
+  solve(ctx, x);
   for (size_t k = 0; k < 5; k++) {
     size_t j = 0;                                   /* idamax: first index of the largest |x| (source_iamax_r.h) */
     double big = 0.0;
     for (size_t i = 0; i < n; i++) if (fabs(x[i]) > big) { big = fabs(x[i]); j = i; }
     for (size_t i = 0; i < n; i++) v[i] = 0.0;
     v[j] = 1.0;
-    oracle_cholesky_svx(n, llt, lda, v);
+    solve(ctx, v);
     gamma_old = gamma;
     gamma = asum(n, v);
     int same = 1;
@@ -212,13 +208,28 @@ int oracle_cholesky_rcond(size_t n, const double *llt, size_t lda, double *rcond
     if (same || gamma < gamma_old) break;
     for (size_t i = 0; i < n; i++) xi[i] = v[i] >= 0.0 ? 1 : -1;
     for (size_t i = 0; i < n; i++) x[i] = xi[i];
-    oracle_cholesky_svx(n, llt, lda, x);
+    solve(ctx, x);
   }
   double temp = 1.0;
   for (size_t i = 0; i < n; i++) { x[i] = temp * (1.0 + (double)i / ((double)n - 1.0)); temp = -temp; }
-  oracle_cholesky_svx(n, llt, lda, x);
+  solve(ctx, x);
   temp = 2.0 * asum(n, x) / (3.0 * (double)n);
   if (temp > gamma) gamma = temp;
+  return gamma;
+}
+
+struct chol_ctx { size_t n, lda; const double *m; const size_t *perm; };
+static void chol_solve_cb(void *c, double *x) { struct chol_ctx *q = (struct chol_ctx *)c; oracle_cholesky_svx(q->n, q->m, q->lda, x); }
+
+/* gsl_linalg_cholesky_rcond (cholesky.c:499-537), A^-1 = L^-T L^-1 (cholesky.c:584-604) */
+int oracle_cholesky_rcond(size_t n, const double *llt, size_t lda, double *rcond, double *work)
+{
+  *rcond = 0.0;
+  if (n == 0) return ORACLE_SUCCESS;
+  const double anorm = cholesky_norm1(n, llt, lda, work);
+  if (anorm == 0.0) return ORACLE_SUCCESS;
+  struct chol_ctx c = {n, lda, llt, NULL};
+  const double gamma = invnorm1(n, chol_solve_cb, &c, work);
   if (gamma != 0.0) *rcond = (1.0 / anorm) / gamma;
   return ORACLE_SUCCESS;
 }
@@ -285,5 +296,67 @@ int oracle_pcholesky_svx(size_t n, const double *ldlt, size_t lda, const size_t 
   for (size_t i = 0; i < n; i++) tmp[perm[i]] = x[i];                           /* permute_vector_inverse */
   for (size_t i = 0; i < n; i++) x[i] = tmp[i];
   free(tmp);
+  return ORACLE_SUCCESS;
+}
+
+
+/* linalg/pcholesky.c:231-273: keep A in the upper triangle, scale (cholesky.c:312-388), pivoted LDL^T of S A S */
+int oracle_pcholesky_decomp2(size_t n, double *a, size_t lda, size_t *perm, double *s)
+{
+  for (size_t i = 0; i < n; i++)
+    for (size_t j = 0; j < i; j++) a[j * lda + i] = a[i * lda + j];
+  for (size_t i = 0; i < n; i++) {
+    const double aii = a[i * lda + i];
+    s[i] = aii <= 0.0 ? 1.0 : 1.0 / sqrt(aii);
+  }
+  for (size_t j = 0; j < n; j++)
+    for (size_t i = j; i < n; i++) a[i * lda + j] *= s[i] * s[j];
+  /* pcholesky_decomp(copy_uplo = 0): the shared decomposition copies the lower triangle up first, which would
+     overwrite the saved original -- save and restore the strict upper triangle around it */
+  double *up = (double *)malloc(n * n * sizeof(double));
+  if (!up) return ORACLE_FAILURE;
+  for (size_t i = 0; i < n; i++) for (size_t j = i + 1; j < n; j++) up[i * n + j] = a[i * lda + j];
+  const int st = oracle_pcholesky_decomp(n, a, lda, perm);
+  for (size_t i = 0; i < n; i++) for (size_t j = i + 1; j < n; j++) a[i * lda + j] = up[i * n + j];
+  free(up);
+  return st;
+}
+
+/* linalg/pcholesky.c:314-353 */
+int oracle_pcholesky_svx2(size_t n, const double *ldlt, size_t lda, const size_t *perm, const double *s, double *x)
+{
+  for (size_t i = 0; i < n; i++) x[i] *= s[i];
+  oracle_pcholesky_svx(n, ldlt, lda, perm, x);
+  for (size_t i = 0; i < n; i++) x[i] *= s[i];
+  return ORACLE_SUCCESS;
+}
+
+static void pchol_solve_cb(void *c, double *x) { struct chol_ctx *q = (struct chol_ctx *)c; oracle_pcholesky_svx(q->n, q->m, q->lda, q->perm, x); }
+
+/* linalg/pcholesky.c:472-580: 1-norm of the matrix kept in the strict upper triangle with its diagonal rebuilt
+   from L D L^T (in pivoted order, then un-permuted), times the estimate of |A^-1|_1; work: 3 n */
+int oracle_pcholesky_rcond(size_t n, const double *ldlt, size_t lda, const size_t *perm, double *rcond, double *work)
+{
+  *rcond = 0.0;
+  if (n == 0) return ORACLE_SUCCESS;
+  double *diag = work + n, *tmp = work + 2 * n;
+  for (size_t j = 0; j < n; j++) {
+    double ajj = ldlt[j * lda + j];
+    for (size_t i = 0; i < j; i++) { const double di = ldlt[i * lda + i], l = ldlt[j * lda + i]; ajj += di * l * l; }
+    tmp[j] = ajj;
+  }
+  for (size_t i = 0; i < n; i++) diag[perm[i]] = tmp[i];          /* gsl_permute_vector_inverse */
+  for (size_t i = 0; i < n; i++) work[i] = 0.0;
+  double anorm = 0.0;
+  for (size_t j = 0; j < n; j++) {
+    double sum = 0.0;
+    for (size_t i = 0; i < j; i++) { const double v = fabs(ldlt[i * lda + j]); sum += v; work[i] += v; }
+    work[j] = sum + fabs(diag[j]);
+  }
+  for (size_t i = 0; i < n; i++) if (work[i] > anorm) anorm = work[i];
+  if (anorm == 0.0) return ORACLE_SUCCESS;
+  struct chol_ctx c = {n, lda, ldlt, perm};
+  const double gamma = invnorm1(n, pchol_solve_cb, &c, work);
+  if (gamma != 0.0) *rcond = (1.0 / anorm) / gamma;
   return ORACLE_SUCCESS;
 }

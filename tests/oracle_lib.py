@@ -224,6 +224,28 @@ def pcholesky_solve(ldlt, perm, b):
     return x
 
 
+def pcholesky_decomp2(a):
+    a = np.array(a, dtype=np.float64, order="C")
+    perm = np.zeros(a.shape[0], dtype=np.uintp)
+    s = np.empty(a.shape[0])
+    st = lib().oracle_pcholesky_decomp2(_sz(a.shape[0]), _p(a), _sz(a.shape[1]), perm.ctypes.data_as(C.POINTER(C.c_size_t)), _p(s))
+    return st, a, perm, s
+
+
+def pcholesky_solve2(ldlt, perm, s, b):
+    x = np.array(b, dtype=np.float64)
+    lib().oracle_pcholesky_svx2(_sz(ldlt.shape[0]), _p(ldlt), _sz(ldlt.shape[1]), perm.ctypes.data_as(C.POINTER(C.c_size_t)), _p(s), _p(x))
+    return x
+
+
+def pcholesky_rcond(ldlt, perm):
+    n = ldlt.shape[0]
+    r = C.c_double(0)
+    work = np.zeros(3 * n)
+    lib().oracle_pcholesky_rcond(_sz(n), _p(ldlt), _sz(ldlt.shape[1]), perm.ctypes.data_as(C.POINTER(C.c_size_t)), C.byref(r), _p(work))
+    return r.value
+
+
 # ---- RBF harness
 def rbf_fill(kind, eps, x):
     n, d = x.shape

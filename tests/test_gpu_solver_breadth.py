@@ -189,3 +189,44 @@ def test_facade_solver_choice_and_rcond(pkg, orc, solver):
     st, got, _ = t.eval_many(y)
     want = orc.rbf_eval(1, 0.0, x, orc.rbf_solve(1, 0.0, x, f), y)
     assert st == 0 and np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n", [3, 12, 50, 400])
+def test_pcholesky_decomp2_svx2_bitexact_and_rcond_table(pkg, orc, n):
+    """gsl_linalg_pcholesky_decomp2 / _svx2 / _rcond (linalg/pcholesky.c:231-353, 472-580).  The scaled, pivoted LDL^T has the
+    pivots and the BITS of the oracle's restatement (no FMA contraction on either side); the solve agrees to rounding;
+    rcond reproduces the reference-held Hilbert table (linalg/test_cholesky.c:54-57, 675-687: 1e-6) and the oracle."""
+    ctx = pkg.HipContext.on_torch_stream(0)
+    a = posdef(n, 500 + n) * np.outer(np.linspace(1.0, 20.0, n), np.linspace(1.0, 20.0, n))
+    st_o, ldlt_o, perm_o, s_o = orc.pcholesky_decomp2(a)
+    d_a, d_p, d_s = dev(a), torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")
+    ctx.pcholesky_decomp2(n, ptr(d_a), n, ptr(d_p), ptr(d_s))
+    ctx.sync()
+    assert np.array_equal(d_s.cpu().numpy(), s_o)
+    assert np.array_equal(d_p.cpu().numpy().astype(np.uintp), perm_o)
+    assert np.array_equal(d_a.cpu().numpy(), ldlt_o)
+    assert np.array_equal(np.triu(ldlt_o, 1), np.triu(a, 1))                   # the UNSCALED matrix above the diagonal
+    sol = np.random.default_rng(n).random(n)
+    d_x = dev(a @ sol)
+    ctx.pcholesky_svx2(n, ptr(d_a), n, ptr(d_p), ptr(d_s), ptr(d_x))
+    ctx.sync()
+    x_o = orc.pcholesky_solve2(ldlt_o, perm_o, s_o, a @ sol)
+    got = d_x.cpu().numpy()
+    assert np.abs(got - x_o).max() <= 1e-10 * np.abs(x_o).max() and np.abs(got - sol).max() <= 64.0 * n * EPS * 20
+    # rcond: the unscaled decomposition (what the reference's test calls it on)
+    b = posdef(n, 900 + n)
+    st_b, ldlt_b, perm_b = orc.pcholesky_decomp(b)
+    d_b, d_pb = dev(b), torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.pcholesky_decomp(n, ptr(d_b), n, ptr(d_pb))
+    r, r_o = ctx.pcholesky_rcond(n, ptr(d_b), n, ptr(d_pb)), orc.pcholesky_rcond(ldlt_b, perm_b)
+    true_rcond = 1.0 / (np.abs(b).sum(axis=0).max() * np.abs(np.linalg.inv(b)).sum(axis=0).max())
+    assert abs(r - r_o) <= 1e-6 * r_o and true_rcond * (1 - 1e-8) <= r <= 3.0 * true_rcond
+    if n == 3:
+        spec = LINALG["hilbert_rcond"]
+        for m, want in enumerate(spec["values"], start=1):
+            if want <= 1.0e-12:
+                continue
+            d_h, d_ph = dev(hilbert(m)), torch.empty(m, dtype=torch.int32, device="cuda")
+            ctx.pcholesky_decomp(m, ptr(d_h), m, ptr(d_ph))
+            got_r = ctx.pcholesky_rcond(m, ptr(d_h), m, ptr(d_ph))
+            assert abs(got_r - want) <= 1.0e-6 * want, (m, got_r, want)

@@ -239,6 +239,35 @@ def test_pcholesky_reconstructs_and_solves(orc, n):
         assert np.abs(x - sol).max() <= tol["pcholesky_solve_hilbert_eps_mult_per_n"] * n * EPS * 4
 
 
+def test_pcholesky_rcond_hilbert_table_and_decomp2(orc):
+    """gsl_linalg_pcholesky_rcond is pinned by the same reference-held table as cholesky_rcond: the reference's own test
+    (linalg/test_cholesky.c:675-687, 716-725) compares it with hilb_rcond to 1e-6 for the UNSCALED decomposition.
+    decomp2 / svx2 (pcholesky.c:231-353): the unscaled matrix in the strict upper triangle, L D L^T = P S A S P^T to the
+    reference's 1024 N eps, solutions to its 64 N eps (random) / 2048 N eps (Hilbert) (test_cholesky.c:712-713, 794-802)."""
+    spec = LINALG["hilbert_rcond"]
+    for n, want in enumerate(spec["values"], start=1):
+        if want <= 1.0e-12:                                          # test_cholesky.c:719-720
+            continue
+        st, ldlt, perm = orc.pcholesky_decomp(hilbert(n))
+        assert st == 0
+        got = orc.pcholesky_rcond(ldlt, perm)
+        assert abs(got - want) <= 1.0e-6 * want, (n, got, want)
+    for n in (1, 2, 5, 12, 40):
+        for a in [posdef(n, 300 + n)] + ([hilbert(n)] if n <= 12 else []):
+            st, ldlt, perm, sc = orc.pcholesky_decomp2(a)
+            assert st == 0 and np.array_equal(sc, 1.0 / np.sqrt(np.diag(a)))
+            assert np.array_equal(np.triu(ldlt, 1), np.triu(a, 1))   # the UNSCALED original above the diagonal
+            L = np.tril(ldlt, -1) + np.eye(n)
+            D = np.diag(np.diag(ldlt))
+            scaled = a * np.outer(sc, sc)
+            assert np.abs(L @ D @ L.T - scaled[np.ix_(perm, perm)]).max() <= 1024.0 * n * EPS * np.abs(scaled).max()
+            sol = np.random.default_rng(n).random(n)
+            x = orc.pcholesky_solve2(ldlt, perm, sc, a @ sol)
+            mult = 2048.0 if (n <= 12 and a is not None and np.allclose(a, hilbert(n))) else 64.0
+            if n <= 5 or mult == 64.0:
+                assert np.abs(x - sol).max() <= mult * n * EPS * 8 * max(1.0, np.linalg.cond(a) * 1e-3)
+
+
 @pytest.mark.parametrize("n", [2, 3, 4, 12])
 def test_lu_refine_keeps_the_known_answers(orc, n):
     """linalg/test.c:411-494: after LU_solve, LU_refine must still meet the Hilbert / Vandermonde tolerances."""
