@@ -874,7 +874,8 @@ static int bary_eval_part(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_r
   bool sorted = false;
   if (will_sort) {
     /* bin by the data's bounding box when tree_pack kept one for these records: saves the pass over the targets */
-    int st = sinterp_sort_reorder(ctx, d_targets, m, ttda, 2, 64, &srt, m_cap, slot,
+    const int per_cell = getenv("GSL_SINTERP_BARY_PER_CELL") ? atoi(getenv("GSL_SINTERP_BARY_PER_CELL")) : 64;   /* developer */
+    int st = sinterp_sort_reorder(ctx, d_targets, m, ttda, 2, per_cell, &srt, m_cap, slot,
                                   have_table ? (const unsigned long long *)ctx->d_jumpt : (const unsigned long long *)NULL);
     if (st) return st;
     sorted = true;

@@ -41,7 +41,7 @@ struct DagTask {            /* 16 bytes, read by the device */
 
 struct DagCost {            /* microseconds; calibrated on MI355X (tools/dag_calibrate.py) */
   double step256, step128;  /* one 16-wide K-step of a 256 x 128 / 128 x 128 update */
-  double upd_fixed;         /* poll + acquire + C tile load + ring fill + store + release */
+  double upd_fixed256, upd_fixed128;   /* poll + acquire + C tile load + ring fill + store + release */
   double fused_step, fused_fixed, fused_trsm;
   double potrf, chain_trsm, chain_syrk, chain_pub;
   int kcb;                  /* far updates wait for chunks of kcb column blocks */
@@ -52,7 +52,7 @@ struct DagCost {            /* microseconds; calibrated on MI355X (tools/dag_cal
 static inline DagCost dag_default_cost(int T)
 {
   DagCost c;
-  c.step256 = 4.0; c.step128 = 2.4; c.upd_fixed = 9.0;
+  c.step256 = 4.0; c.step128 = 2.4; c.upd_fixed256 = 9.0; c.upd_fixed128 = 9.0;
   c.fused_step = 2.6; c.fused_fixed = 11.0; c.fused_trsm = 9.0;
   c.potrf = 26.0; c.chain_trsm = 9.0; c.chain_syrk = 10.0; c.chain_pub = 2.0;
   c.kcb = T >= 96 ? 8 : (T >= 48 ? 4 : 2);
@@ -152,7 +152,6 @@ static inline void dag_build_schedule(int T, int workers, const DagCost &cm, Dag
      alone; a block that a frontier update has already carried past the chunk is skipped. */
   auto pair_candidate = [&](int m, Cand *c) -> bool {
     const int r0 = 2 * m, r1 = std::min(2 * m + 1, T - 1);
-    const int front = cj;
     for (int guard = 0; guard < 4 * T; guard++) {
       const int c0 = far_c[m];
       int j = far_j[m];
@@ -178,7 +177,7 @@ static inline void dag_build_schedule(int T, int workers, const DagCost &cm, Dag
   auto duration = [&](const Cand &c) -> double {
     const int kb = c.k1 - c.k0;
     if (c.type == DAG_FUSED) return cm.fused_fixed + kb * 8 * cm.fused_step + cm.fused_trsm;
-    return cm.upd_fixed + kb * 8 * (c.nr == 2 ? cm.step256 : cm.step128);
+    return c.nr == 2 ? cm.upd_fixed256 + kb * 8 * cm.step256 : cm.upd_fixed128 + kb * 8 * cm.step128;
   };
 
   /* Two worker pools, two lists.  Express workers only take the tasks of the rows right behind the chain

@@ -160,6 +160,9 @@ int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double 
                                int nrhs);
 /* gsl_sinterp_hip_cholesky_decomp1 for an input that is stored symmetrically (both triangles valid) */
 int sinterp_cholesky_decomp1_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info);
+/* chol_dag.hip: the factorisation as one persistent task-DAG launch (n a multiple of 128); *h_done = 0: not run */
+bool sinterp_cholesky_dag_applicable(size_t n, const double *d_a, size_t lda);
+int sinterp_cholesky_dag(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, int *h_done);
 /* second grow-only buffer for vectors that must outlive factorisation workspaces */
 int sinterp_aux(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 int sinterp_invbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
@@ -177,6 +180,9 @@ struct sinterp_sorted {
   int *ls;                      /* [m] leaf indices in cell order (barycentric sweep) */
   unsigned *cellid, *slot, *offset;
   unsigned long long *box;      /* bounding-box keys, box[2c] = min, box[2c+1] = max */
+  bool two_level;               /* large batches (sort.hip, "two-level reorder"): slot[k] = position in the coarse order, */
+  unsigned *fin;                /*   fin[coarse position] = position in cell order, */
+  double *res1;                 /*   res1 = the results in the coarse order (first hop of the un-sort) */
 };
 int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
                          sinterp_sorted *out, size_t m_cap, int slot, const unsigned long long *box_in);

@@ -340,6 +340,148 @@ unsort_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ 
   }
 }
 
+
+/* ---- two-level reorder (large batches) --------------------------------------------------------
+   Every pass of the one-atomic-per-point scheme above that touches a RANDOM line per point costs 0.2 - 0.4 ms per 10^7
+   points on this memory system, whatever the operation: the histogram's returning atomics (tools/atomics_study:
+   400 us with the table shared, private to the XCD, or at any scope -- it is the line rate, not the atomic), the
+   16-byte scatter (285 us), the gather of the un-sort (216 us); a sequential pass over the same points costs 40 - 60 us.
+   Here the points are first partitioned into <= 1024 coarse bins (runs of consecutive cells) with workgroup-private LDS
+   histograms -- no global atomic, every write lands in a run of the workgroup's chunk -- and then ordered by cell inside
+   windows of TL_W consecutive cells, again in LDS, with one global atomic per (unit, occupied cell) to reserve the unit's
+   share of the cell.  Only the final gather of the un-sort remains a random pass:
+       A  coarse histogram      cellid[k];  cnt[bin][workgroup]          (sequential read, LDS atomics)
+          scan of cnt           -> first position of every (bin, workgroup) run
+       B  coarse scatter        t_y / t_c[p1] = point / cell, pos1[k] = p1 (runs of ~CH/NB points)
+       C1 fine histogram        per unit of TL_P consecutive p1: LDS counts of its cells, one atomicAdd per occupied cell
+          scan of count         -> offset[cell]                            (as in the one-level scheme)
+       C2 fine scatter          ys[p] = t_y[p1], fin[p1] = p               (p within the window: local writes)
+       un-sort                  res1[p1] = vs[fin[p1]] (local gather), values[k] = res1[pos1[k]] (the random pass)
+   A point whose cell lies outside its unit's window (sparse regions: a unit spanning > TL_W cells holds < 4 points per
+   cell) takes the one-level route for that point: slot by a global atomic in C1, position in C2.  The order inside a
+   cell is arbitrary (as before); results do not depend on it. */
+#define TL_CH 16384
+#define TL_P 8192
+#define TL_W 2048
+#define TL_NB 1024
+#define TL_MIN_M (1u << 18)
+
+__global__ void __launch_bounds__(256)
+tl_coarse_hist_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, int g, const unsigned long long *__restrict__ box,
+                      int shift, unsigned nb, unsigned nwg, unsigned *__restrict__ cellid, unsigned *__restrict__ cnt)
+{
+  __shared__ unsigned h[TL_NB];
+  for (int i = threadIdx.x; i < TL_NB; i += 256) h[i] = 0;
+  __syncthreads();
+  const size_t k0 = (size_t)blockIdx.x * TL_CH, k1 = k0 + TL_CH < m ? k0 + TL_CH : m;
+  for (size_t k = k0 + threadIdx.x; k < k1; k += 256) {
+    const unsigned c = cell_of(y, k, ytda, dim, g, box);
+    cellid[k] = c;
+    atomicAdd(&h[c >> shift], 1u);
+  }
+  __syncthreads();
+  for (unsigned b = threadIdx.x; b < nb; b += 256) cnt[(size_t)b * nwg + blockIdx.x] = h[b];
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+tl_coarse_scatter_kernel(const double *__restrict__ y, size_t m, size_t ytda, const unsigned *__restrict__ cellid, int shift, unsigned nb,
+                         unsigned nwg, const unsigned *__restrict__ cnt, double *__restrict__ t_y, unsigned *__restrict__ t_c,
+                         unsigned *__restrict__ pos1)
+{
+  __shared__ unsigned base[TL_NB], cur[TL_NB];
+  for (unsigned b = threadIdx.x; b < TL_NB; b += 256) { base[b] = b < nb ? cnt[(size_t)b * nwg + blockIdx.x] : 0u; cur[b] = 0; }
+  __syncthreads();
+  const size_t k0 = (size_t)blockIdx.x * TL_CH, k1 = k0 + TL_CH < m ? k0 + TL_CH : m;
+  for (size_t k = k0 + threadIdx.x; k < k1; k += 256) {
+    const unsigned c = cellid[k], b = c >> shift;
+    const unsigned p = base[b] + atomicAdd(&cur[b], 1u);
+    if (DIM == 2) *reinterpret_cast<double2 *>(t_y + (size_t)p * 2) = make_double2(y[k * ytda], y[k * ytda + 1]);
+    else
+      for (int d = 0; d < DIM; d++) t_y[(size_t)p * DIM + d] = y[k * ytda + d];
+    t_c[p] = c;
+    pos1[k] = p;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+tl_fine_hist_kernel(const unsigned *__restrict__ t_c, size_t m, int shift, unsigned *__restrict__ count, unsigned *__restrict__ ubase,
+                    unsigned *__restrict__ fin)
+{
+  __shared__ unsigned h[TL_W];
+  for (int i = threadIdx.x; i < TL_W; i += 256) h[i] = 0;
+  __syncthreads();
+  const size_t i0 = (size_t)blockIdx.x * TL_P, i1 = i0 + TL_P < m ? i0 + TL_P : m;
+  const unsigned c_first = (t_c[i0] >> shift) << shift;   /* bins ascend along p1: no cell of the unit is below its first point's bin */
+  for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const unsigned c = t_c[i], d = c - c_first;
+    if (d < TL_W) atomicAdd(&h[d], 1u);
+    else fin[i] = atomicAdd(&count[c], 1u);
+  }
+  __syncthreads();
+  for (unsigned d = threadIdx.x; d < TL_W; d += 256)
+    if (h[d]) ubase[(size_t)blockIdx.x * TL_W + d] = atomicAdd(&count[c_first + d], h[d]);
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+tl_fine_scatter_kernel(const double *__restrict__ t_y, const unsigned *__restrict__ t_c, size_t m, int shift,
+                       const unsigned *__restrict__ offset, const unsigned *__restrict__ ubase, unsigned *__restrict__ fin,
+                       double *__restrict__ ys)
+{
+  __shared__ unsigned ub[TL_W], cur[TL_W];
+  for (unsigned d = threadIdx.x; d < TL_W; d += 256) { ub[d] = ubase[(size_t)blockIdx.x * TL_W + d]; cur[d] = 0; }   /* unused entries: never read */
+  __syncthreads();
+  const size_t i0 = (size_t)blockIdx.x * TL_P, i1 = i0 + TL_P < m ? i0 + TL_P : m;
+  const unsigned c_first = (t_c[i0] >> shift) << shift;
+  for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const unsigned c = t_c[i], d = c - c_first;
+    const unsigned p = offset[c] + (d < TL_W ? ub[d] + atomicAdd(&cur[d], 1u) : fin[i]);
+    if (DIM == 2) *reinterpret_cast<double2 *>(ys + (size_t)p * 2) = *reinterpret_cast<const double2 *>(t_y + i * 2);
+    else
+      for (int q = 0; q < DIM; q++) ys[(size_t)p * DIM + q] = t_y[i * DIM + q];
+    fin[i] = p;
+  }
+}
+
+/* un-sort, first hop: results from cell order back to the coarse order (a gather inside the unit's window) */
+template <int PACKED>
+__global__ void __launch_bounds__(256)
+tl_unsort_local_kernel(const unsigned *__restrict__ fin, size_t m, const double *__restrict__ vs, const int *__restrict__ ls,
+                       double *__restrict__ res)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    const size_t p = fin[i];
+    if (PACKED == 1) reinterpret_cast<double2 *>(res)[i] = reinterpret_cast<const double2 *>(vs)[p];
+    else if (PACKED == 2) reinterpret_cast<double2 *>(res)[i] = make_double2(vs[p], __longlong_as_double((long long)ls[p]));
+    else res[i] = vs[p];
+  }
+}
+
+/* second hop: the one random gather, 16 (8) bytes per target */
+template <int PACKED>
+__global__ void __launch_bounds__(256)
+tl_unsort_final_kernel(const unsigned *__restrict__ pos1, size_t m, const double *__restrict__ res, double *__restrict__ values,
+                       int *__restrict__ leaf)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    const size_t p = pos1[k];
+    if (PACKED) {
+      const double2 r = reinterpret_cast<const double2 *>(res)[p];
+      if (values) values[k] = r.x;
+      if (leaf) leaf[k] = (int)__double_as_longlong(r.y);
+    } else values[k] = res[p];
+  }
+}
+
+static bool sort_two_level(size_t m)
+{
+  const char *e = getenv("GSL_SINTERP_SORT_TWO_LEVEL");      /* opt-in; read per call: the tests compare both routes in one process */
+  return e && e[0] == '1' && m >= TL_MIN_M;
+}
+
 /* m_cap >= m sizes the buffer section (two sections -- `slot` 0 / 1 -- so that two chunks of one batch can be in
    flight on two streams); box_in != NULL: bounding-box keys to bin by (e.g. the data's box kept with the jump table)
    instead of a pass over the targets -- points outside it land in the border cells, which only costs locality */
@@ -363,11 +505,18 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
     for (int c = 0; c < dim; c++) ncell_cap *= (size_t)gc;
     if (ncell_cap < ncell) ncell_cap = ncell;
   }
-  /* layout: box | ys | vs | ls | cellid | slot | count(+1) ; every section 16-byte aligned */
+  /* layout: box | ys | vs | ls | cellid | slot | count(+1) [| t_y | t_c | fin | cnt | ubase : two-level] ; every section
+     16-byte aligned */
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const bool two = sort_two_level(m_cap) && dim >= 1 && dim <= 3;
+  const size_t nwg_cap = (m_cap + TL_CH - 1) / TL_CH, nu_cap = (m_cap + TL_P - 1) / TL_P;
+  const size_t cnt_n = (size_t)TL_NB * nwg_cap;
   const size_t o_ys = 64, o_vs = o_ys + up(m_cap * dim * 8), o_ls = o_vs + up(m_cap * 16), o_cell = o_ls + up(m_cap * 4),
                o_slot = o_cell + up(m_cap * 4), o_cnt = o_slot + up(m_cap * 4),
-               bytes = (o_cnt + up((ncell_cap + 1) * 4 + (ncell_cap / 1024 + 8) * 4) + 255) & ~(size_t)255;
+               o_ty = o_cnt + up((ncell_cap + 1) * 4 + (ncell_cap / 1024 + 8) * 4),
+               o_tc = o_ty + (two ? up(m_cap * (dim * 8 > 16 ? dim * 8 : 16)) : 0), o_fin = o_tc + (two ? up(m_cap * 4) : 0),
+               o_ca = o_fin + (two ? up(m_cap * 4) : 0), o_ub = o_ca + (two ? up((cnt_n + 1) * 4 + (cnt_n / 1024 + 8) * 4) : 0),
+               bytes = (o_ub + (two ? up(nu_cap * TL_W * 4) : 0) + 255) & ~(size_t)255;
   void *buf = NULL;
   int st = sinterp_sortbuf(ctx, bytes * (slot >= 0 ? 2 : 1), &buf);
   if (st) return st;
@@ -375,6 +524,8 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   out->box = (unsigned long long *)b;
   out->ys = (double *)(b + o_ys); out->vs = (double *)(b + o_vs); out->ls = (int *)(b + o_ls);
   out->cellid = (unsigned *)(b + o_cell); out->slot = (unsigned *)(b + o_slot); out->offset = (unsigned *)(b + o_cnt);
+  out->two_level = two && m >= TL_MIN_M;
+  out->fin = (unsigned *)(b + o_fin); out->res1 = (double *)(b + o_ty);
   HIP_OK(ctx, hipMemsetAsync(out->offset, 0, ncell * 4, ctx->stream));
   size_t blocks = (m + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -384,6 +535,38 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
     hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, out->box);
     box = out->box;
   } else out->box = (unsigned long long *)box_in;
+  if (out->two_level) {
+    int shift = 0;
+    while (((ncell - 1) >> shift) >= TL_NB) shift++;
+    const unsigned nb = (unsigned)((ncell - 1) >> shift) + 1u, nwg = (unsigned)((m + TL_CH - 1) / TL_CH), nu = (unsigned)((m + TL_P - 1) / TL_P);
+    double *t_y = (double *)(b + o_ty);
+    unsigned *t_c = (unsigned *)(b + o_tc), *cnt = (unsigned *)(b + o_ca), *ubase = (unsigned *)(b + o_ub);
+    const size_t nc = (size_t)nb * nwg;
+    hipLaunchKernelGGL(tl_coarse_hist_kernel, dim3(nwg), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g, box, shift, nb, nwg, out->cellid, cnt);
+    launch_cell_scan(ctx, cnt, nc, cnt + nc + 1);
+    if (dim == 2)
+      hipLaunchKernelGGL(tl_coarse_scatter_kernel<2>, dim3(nwg), dim3(256), 0, ctx->stream, d_y, m, ytda, (const unsigned *)out->cellid, shift, nb,
+                         nwg, (const unsigned *)cnt, t_y, t_c, out->slot);
+    else if (dim == 3)
+      hipLaunchKernelGGL(tl_coarse_scatter_kernel<3>, dim3(nwg), dim3(256), 0, ctx->stream, d_y, m, ytda, (const unsigned *)out->cellid, shift, nb,
+                         nwg, (const unsigned *)cnt, t_y, t_c, out->slot);
+    else
+      hipLaunchKernelGGL(tl_coarse_scatter_kernel<1>, dim3(nwg), dim3(256), 0, ctx->stream, d_y, m, ytda, (const unsigned *)out->cellid, shift, nb,
+                         nwg, (const unsigned *)cnt, t_y, t_c, out->slot);
+    hipLaunchKernelGGL(tl_fine_hist_kernel, dim3(nu), dim3(256), 0, ctx->stream, (const unsigned *)t_c, m, shift, out->offset, ubase, out->fin);
+    launch_cell_scan(ctx, out->offset, ncell, out->offset + ncell + 1);
+    if (dim == 2)
+      hipLaunchKernelGGL(tl_fine_scatter_kernel<2>, dim3(nu), dim3(256), 0, ctx->stream, (const double *)t_y, (const unsigned *)t_c, m, shift,
+                         (const unsigned *)out->offset, (const unsigned *)ubase, out->fin, out->ys);
+    else if (dim == 3)
+      hipLaunchKernelGGL(tl_fine_scatter_kernel<3>, dim3(nu), dim3(256), 0, ctx->stream, (const double *)t_y, (const unsigned *)t_c, m, shift,
+                         (const unsigned *)out->offset, (const unsigned *)ubase, out->fin, out->ys);
+    else
+      hipLaunchKernelGGL(tl_fine_scatter_kernel<1>, dim3(nu), dim3(256), 0, ctx->stream, (const double *)t_y, (const unsigned *)t_c, m, shift,
+                         (const unsigned *)out->offset, (const unsigned *)ubase, out->fin, out->ys);
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
   hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g,
                      box, out->cellid, out->slot, out->offset);
   launch_cell_scan(ctx, out->offset, ncell, out->offset + ncell + 1);
@@ -411,6 +594,14 @@ int sinterp_unsort_packed(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, siz
   if (m == 0) return ST_SUCCESS;
   size_t blocks = (m + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  if (s->two_level) {
+    hipLaunchKernelGGL(tl_unsort_local_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->fin, m,
+                       (const double *)s->vs, (const int *)NULL, s->res1);
+    hipLaunchKernelGGL(tl_unsort_final_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
+                       (const double *)s->res1, d_values, d_leaf);
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
   hipLaunchKernelGGL(unsort_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->cellid,
                      (const unsigned *)s->slot, (const unsigned *)s->offset, m, (const double2 *)s->vs, d_values, d_leaf);
   LAUNCH_CHECK(ctx);
@@ -422,6 +613,21 @@ int sinterp_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, 
   if (m == 0 || (!d_values && !d_leaf)) return ST_SUCCESS;
   size_t blocks = (m + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  if (s->two_level) {
+    if (d_leaf) {
+      hipLaunchKernelGGL(tl_unsort_local_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->fin, m,
+                         (const double *)s->vs, (const int *)s->ls, s->res1);
+      hipLaunchKernelGGL(tl_unsort_final_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
+                         (const double *)s->res1, d_values, d_leaf);
+    } else {
+      hipLaunchKernelGGL(tl_unsort_local_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->fin, m,
+                         (const double *)s->vs, (const int *)NULL, s->res1);
+      hipLaunchKernelGGL(tl_unsort_final_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
+                         (const double *)s->res1, d_values, (int *)NULL);
+    }
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
   hipLaunchKernelGGL(unsort_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->cellid,
                      (const unsigned *)s->slot, (const unsigned *)s->offset, m, (const double *)s->vs, d_values,
                      (const int *)s->ls, d_leaf);
