@@ -454,12 +454,17 @@ __device__ __forceinline__ WalkRec lds_rec(const char *p)
   return u.r;
 }
 
-/* packed: values is an array of {value, leaf} pairs (16 bytes, one store here and ONE gather per target in the
-   un-sort pass instead of two) */
+/* packed & 1: values is an array of {value, leaf} pairs (16 bytes, one store here and ONE gather per target in the
+   un-sort pass instead of two).  packed & 2 (two-level reorder, sort.hip): leaf_out is not a leaf array but the map
+   from the position in cell order to the position in the coarse order, where the result is stored. */
 __device__ __forceinline__ void store_result(double *__restrict__ values, int *__restrict__ leaf_out, size_t k, double v, int leaf,
-                                             bool packed)
+                                             int packed)
 {
-  if (packed) {
+  if (packed & 2) {
+    k = reinterpret_cast<const unsigned *>(leaf_out)[k];
+    leaf_out = NULL;
+  }
+  if (packed & 1) {
     *reinterpret_cast<double2 *>(values + 2 * k) = make_double2(v, __longlong_as_double((long long)leaf));
   } else {
     values[k] = v;
@@ -470,7 +475,7 @@ __device__ __forceinline__ void store_result(double *__restrict__ values, int *_
 /* exact coordinates in the located leaf, value and leaf stored (linear_simplex.c:678-711) */
 __device__ __forceinline__ void finish_target(const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, int node, double y0,
                                               double y1, double s0, double s1, size_t k, double *__restrict__ values,
-                                              int *__restrict__ leaf_out, bool packed)
+                                              int *__restrict__ leaf_out, int packed)
 {
   const NodeRec cur = load_rec(rec, node);
   double c0, c1;
@@ -527,7 +532,7 @@ bary_start_kernel(int n_nodes, const NodeRec *__restrict__ rec, const WalkRec *_
     bool in, out;
     classify_affine(cw, y0, y1, in, out);
     if (!in) todo[atomicAdd(todo_count, 1u)] = (int)k;                  /* the exact walk takes it */
-    else if (cw.child[0] == -1) finish_target(rec, tab, node, y0, y1, s0, s1, k, values, leaf_out, packed != 0);
+    else if (cw.child[0] == -1) finish_target(rec, tab, node, y0, y1, s0, s1, k, values, leaf_out, packed);
     else walker = true;
   }
   const unsigned long long wmask = __ballot(walker);
@@ -654,7 +659,7 @@ bary_finish_kernel(const NodeRec *__restrict__ rec, const LeafRec *__restrict__ 
   const int node = wl.st[p].x;
   if (node < 0) return;                                     /* queued for the exact kernel */
   const double2 y = wl.y[p];
-  finish_target(rec, tab, node, y.x, y.y, s0, s1, (size_t)wl.k[p], values, leaf_out, packed != 0);
+  finish_target(rec, tab, node, y.x, y.y, s0, s1, (size_t)wl.k[p], values, leaf_out, packed);
 }
 
 template <bool FAST>
@@ -703,7 +708,7 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
       bool in_cage = false;
       if (!META_SINGULAR(cur.meta)) { solve_node(cur, y0, y1, s0, s1, c0, c1); in_cage = inside_unit(c0, c1); }
       if (!in_cage) {                                   /* linear_simplex.c:341-347 (q7: no abort) */
-        store_result(values, leaf_out, k, __builtin_nan(""), -1, packed != 0);
+        store_result(values, leaf_out, k, __builtin_nan(""), -1, packed);
         atomicAdd(n_outside, 1ULL);
         continue;
       }
@@ -782,7 +787,7 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
     tot += c1;
     if (lr.mask & 2) interp += c1 * lr.f[1];
     if (lr.mask & 4) interp += (1 - tot) * lr.f[2];
-    store_result(values, leaf_out, k, interp, node, packed != 0);
+    store_result(values, leaf_out, k, interp, node, packed);
   }
 }
 
@@ -905,9 +910,10 @@ static int bary_eval_part(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_r
   if (blocks > 65536) blocks = 65536;
   const double *yt = sorted ? (const double *)srt.ys : d_targets;
   const size_t yl = sorted ? (size_t)2 : ttda;
-  double *vt = sorted ? srt.vs : d_values;
-  int *lt = sorted ? (int *)NULL : d_leaf;
-  const int packed = sorted && d_leaf != NULL;             /* {value, leaf} pairs in srt.vs, see store_result */
+  const bool via_map = sorted && srt.two_level;            /* results go to srt.res1 through srt.inv, see store_result */
+  double *vt = sorted ? (via_map ? srt.res1 : srt.vs) : d_values;
+  int *lt = sorted ? (via_map ? (int *)srt.inv : (int *)NULL) : d_leaf;
+  const int packed = (sorted && d_leaf != NULL ? 1 : 0) | (via_map ? 2 : 0);   /* 1: {value, leaf} pairs */
   const int *perm = NULL;
   const unsigned *m_dev = NULL;
   bool side = false;
@@ -959,7 +965,7 @@ static int bary_eval_part(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_r
   LAUNCH_CHECK(ctx);
   if (side) HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[3], 0));   /* join the finish kernel */
   if (sorted) {
-    int st = packed ? sinterp_unsort_packed(ctx, &srt, m, d_values, d_leaf) : sinterp_unsort(ctx, &srt, m, d_values, d_leaf);
+    int st = (packed & 1) ? sinterp_unsort_packed(ctx, &srt, m, d_values, d_leaf) : sinterp_unsort(ctx, &srt, m, d_values, d_leaf);
     if (st) return st;
   }
   return ST_SUCCESS;

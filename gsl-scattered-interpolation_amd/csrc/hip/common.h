@@ -180,12 +180,15 @@ struct sinterp_sorted {
   int *ls;                      /* [m] leaf indices in cell order (barycentric sweep) */
   unsigned *cellid, *slot, *offset;
   unsigned long long *box;      /* bounding-box keys, box[2c] = min, box[2c+1] = max */
-  bool two_level;               /* large batches (sort.hip, "two-level reorder"): slot[k] = position in the coarse order, */
-  unsigned *fin;                /*   fin[coarse position] = position in cell order, */
-  double *res1;                 /*   res1 = the results in the coarse order (first hop of the un-sort) */
+  bool two_level;               /* large batches (sort.hip, "two-level reorder"): slot[k] = position of target k in the coarse order; */
+  unsigned *inv;                /*   inv[p] = coarse position of the target at cell-order position p: the sweep stores the result of */
+  double *res1;                 /*   sorted target p at res1[inv[p]] (8 bytes, or a {value, leaf} pair), NOT at vs[p]; */
+  unsigned *fin;                /*   (internal: slots of the out-of-window points between the two fine passes) */
 };
 int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
                          sinterp_sorted *out, size_t m_cap, int slot, const unsigned long long *box_in);
+/* whether a batch of m targets takes the two-level route (results through inv / res1) */
+bool sinterp_sort_reorder_is_two_level(size_t m);
 int sinterp_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf);
 /* vs holds {value, leaf-as-integer-bits} pairs (16 bytes per target; the vs region is sized for it) */
 int sinterp_unsort_packed(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf);

@@ -179,7 +179,8 @@ __device__ __forceinline__ bool nan_target(const double (&yy)[DIM])
 template <int KIND, int DIM, int TPT>
 __global__ void __launch_bounds__(EV_THREADS)
 rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, const double *__restrict__ w,
-                const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm)
+                const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm,
+                const unsigned *__restrict__ omap)
 {
   __shared__ double s_t0[KIND == GSL_SINTERP_RBF_GAUSSIAN ? TBL_N : 1];
   __shared__ __attribute__((aligned(16))) double s_lt[KIND == GSL_SINTERP_RBF_TPS ? LOG_LDS : 2];
@@ -252,7 +253,7 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
   }
 #pragma unroll
   for (int t = 0; t < TPT; t++)
-    if (kidx[t] < m) s[kidx[t]] = (KIND != GSL_SINTERP_RBF_TPS && nan_target<DIM>(yy[t])) ? NAN : acc[t];
+    if (kidx[t] < m) s[omap ? (size_t)omap[kidx[t]] : kidx[t]] = (KIND != GSL_SINTERP_RBF_TPS && nan_target<DIM>(yy[t])) ? NAN : acc[t];
 }
 
 /* ------------------------------------------------------------------------ */
@@ -315,7 +316,8 @@ centre_pack_kernel(const double *__restrict__ x, size_t n, size_t xtda, const do
 template <int KIND, int DIM, int TPT>
 __global__ void __launch_bounds__(CULL_THREADS)
 rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n, const double *__restrict__ tbox, unsigned ntiles,
-                           const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm)
+                           const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm,
+                const unsigned *__restrict__ omap)
 {
   __shared__ double s_t0[TBL_N];
   __shared__ __attribute__((aligned(16))) double s_c[CT * (DIM + 1)];
@@ -413,12 +415,13 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
   }
 #pragma unroll
   for (int t = 0; t < TPT; t++)
-    if (kidx[t] < m) s[kidx[t]] = nan_target<DIM>(yy[t]) ? NAN : acc[t];
+    if (kidx[t] < m) s[omap ? (size_t)omap[kidx[t]] : kidx[t]] = nan_target<DIM>(yy[t]) ? NAN : acc[t];
 }
 
 template <int KIND, int TPT>
 static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x, size_t n, int dim, size_t xtda, const double *d_w,
-                            const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm, unsigned long long model_id)
+                            const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm, const unsigned *d_omap,
+                            unsigned long long model_id)
 {
   /* the packed centres depend on the model only: reuse them when the caller vouches for the model (model_id != 0) */
   const bool cached = model_id != 0 && ctx->cent_key.id == model_id && ctx->cent_key.x == d_x && ctx->cent_key.w == d_w &&
@@ -440,15 +443,15 @@ static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double 
   switch (dim) {
     case 1:
       if (!cached) hipLaunchKernelGGL((centre_pack_kernel<1>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 1, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 1, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm, d_omap);
       break;
     case 2:
       if (!cached) hipLaunchKernelGGL((centre_pack_kernel<2>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 2, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 2, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm, d_omap);
       break;
     default:
       if (!cached) hipLaunchKernelGGL((centre_pack_kernel<3>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 3, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm);
+      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 3, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm, d_omap);
       break;
   }
   LAUNCH_CHECK(ctx);
@@ -511,14 +514,14 @@ int sinterp_rbf_fill_ex(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const do
 
 template <int KIND, int TPT>
 static int launch_eval(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x, size_t n, int dim, size_t xtda,
-                       const double *d_w, const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm)
+                       const double *d_w, const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm, const unsigned *d_omap)
 {
   const size_t per_block = (size_t)EV_THREADS * TPT;
   dim3 grid((unsigned)((m + per_block - 1) / per_block));
   switch (dim) {
-    case 1: hipLaunchKernelGGL((rbf_eval_kernel<KIND, 1, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, d_x, n, xtda, d_w, d_y, m, ytda, d_s, d_perm); break;
-    case 2: hipLaunchKernelGGL((rbf_eval_kernel<KIND, 2, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, d_x, n, xtda, d_w, d_y, m, ytda, d_s, d_perm); break;
-    default: hipLaunchKernelGGL((rbf_eval_kernel<KIND, 3, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, d_x, n, xtda, d_w, d_y, m, ytda, d_s, d_perm); break;
+    case 1: hipLaunchKernelGGL((rbf_eval_kernel<KIND, 1, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, d_x, n, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap); break;
+    case 2: hipLaunchKernelGGL((rbf_eval_kernel<KIND, 2, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, d_x, n, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap); break;
+    default: hipLaunchKernelGGL((rbf_eval_kernel<KIND, 3, TPT>), grid, dim3(EV_THREADS), 0, ctx->stream, coef, d_x, n, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap); break;
   }
   LAUNCH_CHECK(ctx);
   return ST_SUCCESS;
@@ -530,6 +533,10 @@ extern "C" int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, doub
 {
   return gsl_sinterp_hip_rbf_eval_model(ctx, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, 0ULL);
 }
+
+static int rbf_eval_dispatch(gsl_sinterp_hip_ctx *ctx, int kind, double coef, const double *d_x, size_t n, int dim, size_t xtda,
+                             const double *d_w, const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm,
+                             const unsigned *d_omap, unsigned long long model_id);
 
 extern "C" int gsl_sinterp_hip_rbf_eval_model(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
                                               int dim, size_t xtda, const double *d_w, const double *d_y, size_t m,
@@ -548,10 +555,33 @@ extern "C" int gsl_sinterp_hip_rbf_eval_model(gsl_sinterp_hip_ctx *ctx, int kind
      together (TPS has no decay: nothing to skip, no sort) */
   const bool local = kind != GSL_SINTERP_RBF_TPS;
   int *d_perm = NULL;
+  const unsigned *d_omap = NULL;
   if (local && m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1')) {
+    /* large batches: the targets are physically put in cell order (sort.hip, two-level reorder), swept contiguously, each
+       result stored through the order's map, and the values gathered back -- one random pass instead of the three of
+       the permutation route (histogram atomics, perm scatter, gather + scatter inside the sweep) */
+    if (sinterp_sort_reorder_is_two_level(m)) {
+      sinterp_sorted srt;
+      st = sinterp_sort_reorder(ctx, d_y, m, ytda, dim, 64, &srt, m, -1, (const unsigned long long *)NULL);
+      if (st) return st;
+      if (srt.two_level) {
+        st = rbf_eval_dispatch(ctx, kind, coef, d_x, n, dim, xtda, d_w, (const double *)srt.ys, m, (size_t)dim, srt.res1, (const int *)NULL,
+                               (const unsigned *)srt.inv, model_id);
+        if (st) return st;
+        return sinterp_unsort(ctx, &srt, m, d_s, (int *)NULL);
+      }
+    }
     st = sinterp_sort_targets(ctx, d_y, m, ytda, dim, 64, &d_perm);
     if (st) return st;
   }
+  return rbf_eval_dispatch(ctx, kind, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap, model_id);
+}
+
+static int rbf_eval_dispatch(gsl_sinterp_hip_ctx *ctx, int kind, double coef, const double *d_x, size_t n, int dim, size_t xtda,
+                             const double *d_w, const double *d_y, size_t m, size_t ytda, double *d_s, const int *d_perm,
+                             const unsigned *d_omap, unsigned long long model_id)
+{
+  const bool local = kind != GSL_SINTERP_RBF_TPS;
   /* few targets: 1 per lane keeps more CUs busy; many: 2 per lane for ILP */
   const bool small = m < (size_t)EV_THREADS * 2 * 512;
   static const bool no_cull = getenv("GSL_SINTERP_NO_CULL") && getenv("GSL_SINTERP_NO_CULL")[0] == '1';
@@ -565,17 +595,17 @@ extern "C" int gsl_sinterp_hip_rbf_eval_model(gsl_sinterp_hip_ctx *ctx, int kind
        (C3 sweep 1.70 -> 1.34 ms; 2-D C4: 1.74 vs 1.77 ms, unchanged) */
     const bool small = m < (size_t)CULL_THREADS * 2 * 512 || dim == 3;
     if (kind == GSL_SINTERP_RBF_WENDLAND)
-      return small ? launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, model_id)
-                   : launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, model_id);
-    return small ? launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, model_id)
-                 : launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, model_id);
+      return small ? launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap, model_id)
+                   : launch_eval_cull<GSL_SINTERP_RBF_WENDLAND, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap, model_id);
+    return small ? launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap, model_id)
+                 : launch_eval_cull<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap, model_id);
   }
   if (kind == GSL_SINTERP_RBF_WENDLAND)
-    return small ? launch_eval<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
-                 : launch_eval<GSL_SINTERP_RBF_WENDLAND, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
+    return small ? launch_eval<GSL_SINTERP_RBF_WENDLAND, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap)
+                 : launch_eval<GSL_SINTERP_RBF_WENDLAND, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap);
   if (kind == GSL_SINTERP_RBF_GAUSSIAN)
-    return small ? launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
-                 : launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
-  return small ? launch_eval<GSL_SINTERP_RBF_TPS, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm)
-               : launch_eval<GSL_SINTERP_RBF_TPS, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm);
+    return small ? launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap)
+                 : launch_eval<GSL_SINTERP_RBF_GAUSSIAN, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap);
+  return small ? launch_eval<GSL_SINTERP_RBF_TPS, 1>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap)
+               : launch_eval<GSL_SINTERP_RBF_TPS, 2>(ctx, coef, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, d_perm, d_omap);
 }

@@ -342,124 +342,260 @@ unsort_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ 
 
 
 /* ---- two-level reorder (large batches) --------------------------------------------------------
-   Every pass of the one-atomic-per-point scheme above that touches a RANDOM line per point costs 0.2 - 0.4 ms per 10^7
-   points on this memory system, whatever the operation: the histogram's returning atomics (tools/atomics_study:
-   400 us with the table shared, private to the XCD, or at any scope -- it is the line rate, not the atomic), the
-   16-byte scatter (285 us), the gather of the un-sort (216 us); a sequential pass over the same points costs 40 - 60 us.
-   Here the points are first partitioned into <= 1024 coarse bins (runs of consecutive cells) with workgroup-private LDS
-   histograms -- no global atomic, every write lands in a run of the workgroup's chunk -- and then ordered by cell inside
-   windows of TL_W consecutive cells, again in LDS, with one global atomic per (unit, occupied cell) to reserve the unit's
-   share of the cell.  Only the final gather of the un-sort remains a random pass:
-       A  coarse histogram      cellid[k];  cnt[bin][workgroup]          (sequential read, LDS atomics)
-          scan of cnt           -> first position of every (bin, workgroup) run
-       B  coarse scatter        t_y / t_c[p1] = point / cell, pos1[k] = p1 (runs of ~CH/NB points)
-       C1 fine histogram        per unit of TL_P consecutive p1: LDS counts of its cells, one atomicAdd per occupied cell
-          scan of count         -> offset[cell]                            (as in the one-level scheme)
-       C2 fine scatter          ys[p] = t_y[p1], fin[p1] = p               (p within the window: local writes)
-       un-sort                  res1[p1] = vs[fin[p1]] (local gather), values[k] = res1[pos1[k]] (the random pass)
-   A point whose cell lies outside its unit's window (sparse regions: a unit spanning > TL_W cells holds < 4 points per
-   cell) takes the one-level route for that point: slot by a global atomic in C1, position in C2.  The order inside a
-   cell is arbitrary (as before); results do not depend on it. */
-#define TL_CH 16384
-#define TL_P 8192
+   What a pass costs on this memory system is the number of distinct 64-byte segments its wave instructions touch, not
+   its bytes: every pass of the one-atomic-per-point scheme above that touches one RANDOM segment per point costs
+   0.2 - 0.4 ms per 10^7 points, whatever the operation -- the histogram's returning atomics (tools/atomics_study: 400 us
+   with the table shared, private to the XCD of the issuing workgroup, or at any scope: it is the segment rate, not the
+   atomic), the 16-byte scatter (285 us), the gather of the un-sort (216 us) -- and a first version of this scheme whose
+   scatters were local (inside an L2-resident window) but still one segment per lane was no faster (2.10 vs 1.91 ms at
+   C5).  A sequential pass over the same points costs 40 - 60 us.  So every scattered store here goes through LDS first:
+   a workgroup orders its chunk in LDS and writes RUNS (consecutive lanes -> consecutive addresses).
+       A  coarse histogram   cnt[bin][workgroup], bins = runs of 2^shift consecutive cells, <= TL_NB of them; LDS atomics only
+          scan of cnt        -> first position of every (bin, workgroup) run in the coarse order
+       B  coarse scatter     chunk ordered by bin in LDS, t_y[p1] written in runs of ~CH/NB points; pos1[k] = p1 (sequential)
+       C1 fine histogram     per unit of P consecutive p1: LDS counts over a window of TL_W cells, one global atomicAdd per
+                             occupied (unit, cell) reserves the unit's share of the cell
+          scan of count      -> offset[cell]
+       C2 fine scatter       unit ordered by cell in LDS, ys[p] written in runs (one per occupied cell), inv[p] = p1 beside it
+       sweep                 the consumer stores the result of sorted target p at res1[inv[p]] (a store inside the window)
+       un-sort               values[k] = res1[pos1[k]]: the ONE random pass that is left
+   A point whose cell lies outside its unit's window (sparse regions: a unit spanning > TL_W cells holds < 3 points per
+   cell) takes the one-level route for that point: slot by a global atomic in C1, placed at the tail of the LDS image in
+   C2.  The cell of a point is recomputed from its coordinates in every pass (tl_cell: subtract, multiply by a
+   per-axis factor computed once, truncate -- the same instructions on the same bits each time) instead of being carried
+   along.  The order inside a cell is arbitrary (as before); results do not depend on it. */
+#define TL_NB 256
 #define TL_W 2048
-#define TL_NB 1024
 #define TL_MIN_M (1u << 18)
+#define TL_THREADS 512
+template <int DIM> struct TlGeom {
+  static constexpr int CH = DIM == 3 ? 4096 : 6144;    /* points per workgroup, coarse passes: CH * 8 DIM + 4 CH bytes of LDS */
+  static constexpr int P = 4096;                       /* points per unit, fine passes: P * (8 DIM + 8) bytes + three windows */
+};
 
-__global__ void __launch_bounds__(256)
-tl_coarse_hist_kernel(const double *__restrict__ y, size_t m, size_t ytda, int dim, int g, const unsigned long long *__restrict__ box,
-                      int shift, unsigned nb, unsigned nwg, unsigned *__restrict__ cellid, unsigned *__restrict__ cnt)
+struct TlGrid { double lo[3], f[3]; int g; };          /* cell = sum_c min(g-1, max(0, (int)((y_c - lo_c) f_c))) g^c */
+
+__global__ void tl_grid_kernel(const unsigned long long *__restrict__ box, int dim, int g, TlGrid *__restrict__ out)
 {
-  __shared__ unsigned h[TL_NB];
-  for (int i = threadIdx.x; i < TL_NB; i += 256) h[i] = 0;
-  __syncthreads();
-  const size_t k0 = (size_t)blockIdx.x * TL_CH, k1 = k0 + TL_CH < m ? k0 + TL_CH : m;
-  for (size_t k = k0 + threadIdx.x; k < k1; k += 256) {
-    const unsigned c = cell_of(y, k, ytda, dim, g, box);
-    cellid[k] = c;
-    atomicAdd(&h[c >> shift], 1u);
+  if (threadIdx.x != 0) return;
+  TlGrid t;
+  t.g = g;
+  for (int c = 0; c < 3; c++) {
+    const double lo = c < dim ? dunkey(box[2 * c]) : 0.0, hi = c < dim ? dunkey(box[2 * c + 1]) : 0.0;
+    t.lo[c] = lo;
+    t.f[c] = (c < dim && hi > lo) ? (double)g / (hi - lo) : 0.0;
   }
-  __syncthreads();
-  for (unsigned b = threadIdx.x; b < nb; b += 256) cnt[(size_t)b * nwg + blockIdx.x] = h[b];
+  *out = t;
 }
 
 template <int DIM>
-__global__ void __launch_bounds__(256)
-tl_coarse_scatter_kernel(const double *__restrict__ y, size_t m, size_t ytda, const unsigned *__restrict__ cellid, int shift, unsigned nb,
-                         unsigned nwg, const unsigned *__restrict__ cnt, double *__restrict__ t_y, unsigned *__restrict__ t_c,
-                         unsigned *__restrict__ pos1)
+__device__ __forceinline__ unsigned tl_cell(const TlGrid &t, const double (&v)[DIM])
 {
-  __shared__ unsigned base[TL_NB], cur[TL_NB];
-  for (unsigned b = threadIdx.x; b < TL_NB; b += 256) { base[b] = b < nb ? cnt[(size_t)b * nwg + blockIdx.x] : 0u; cur[b] = 0; }
-  __syncthreads();
-  const size_t k0 = (size_t)blockIdx.x * TL_CH, k1 = k0 + TL_CH < m ? k0 + TL_CH : m;
-  for (size_t k = k0 + threadIdx.x; k < k1; k += 256) {
-    const unsigned c = cellid[k], b = c >> shift;
-    const unsigned p = base[b] + atomicAdd(&cur[b], 1u);
-    if (DIM == 2) *reinterpret_cast<double2 *>(t_y + (size_t)p * 2) = make_double2(y[k * ytda], y[k * ytda + 1]);
-    else
-      for (int d = 0; d < DIM; d++) t_y[(size_t)p * DIM + d] = y[k * ytda + d];
-    t_c[p] = c;
-    pos1[k] = p;
+  unsigned cell = 0;
+#pragma unroll
+  for (int c = DIM - 1; c >= 0; c--) {
+    const double f = __dmul_rn(__dsub_rn(v[c], t.lo[c]), t.f[c]);
+    int i = (f == f) ? (f >= 2147483647.0 ? t.g - 1 : (f <= 0.0 ? 0 : (int)f)) : 0;          /* NaN coordinates go to cell 0 */
+    i = i >= t.g ? t.g - 1 : i;
+    cell = cell * (unsigned)t.g + (unsigned)i;
+  }
+  return cell;
+}
+
+/* ALIGNED: the scheme's own dense [.][DIM] arrays (16-byte aligned); the caller's targets are only known to be doubles */
+template <int DIM, bool ALIGNED = false>
+__device__ __forceinline__ void tl_load(const double *__restrict__ y, size_t k, size_t ytda, double (&v)[DIM])
+{
+  if (ALIGNED && DIM == 2) { const double2 t = *reinterpret_cast<const double2 *>(y + k * 2); v[0] = t.x; v[1] = t.y; }
+  else {
+#pragma unroll
+    for (int c = 0; c < DIM; c++) v[c] = y[k * ytda + c];
   }
 }
 
-__global__ void __launch_bounds__(256)
-tl_fine_hist_kernel(const unsigned *__restrict__ t_c, size_t m, int shift, unsigned *__restrict__ count, unsigned *__restrict__ ubase,
-                    unsigned *__restrict__ fin)
+/* exclusive scan of a[0..n) in LDS by the whole workgroup (n <= 4 * TL_THREADS); returns the total; s_w: 8 words of LDS */
+__device__ __forceinline__ unsigned tl_block_scan(unsigned *a, int n, unsigned *s_w)
 {
-  __shared__ unsigned h[TL_W];
-  for (int i = threadIdx.x; i < TL_W; i += 256) h[i] = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned v[4], sum = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const int i = tid * 4 + q; v[q] = i < n ? a[i] : 0u; sum += v[q]; }
+  unsigned incl = sum;
+  for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+  if (lane == 63) s_w[wave] = incl;
   __syncthreads();
-  const size_t i0 = (size_t)blockIdx.x * TL_P, i1 = i0 + TL_P < m ? i0 + TL_P : m;
-  const unsigned c_first = (t_c[i0] >> shift) << shift;   /* bins ascend along p1: no cell of the unit is below its first point's bin */
-  for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
-    const unsigned c = t_c[i], d = c - c_first;
+  unsigned woff = 0, total = 0;
+  for (int w = 0; w < TL_THREADS / 64; w++) { if (w < wave) woff += s_w[w]; total += s_w[w]; }
+  unsigned run = woff + incl - sum;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const int i = tid * 4 + q; if (i < n) a[i] = run; run += v[q]; }
+  __syncthreads();
+  return total;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(TL_THREADS)
+tl_coarse_hist_kernel(const double *__restrict__ y, size_t m, size_t ytda, const TlGrid *__restrict__ grid, int shift, unsigned nb,
+                      unsigned nwg, unsigned *__restrict__ cnt)
+{
+  constexpr int CH = TlGeom<DIM>::CH;
+  __shared__ unsigned h[TL_NB];
+  const TlGrid t = *grid;
+  for (int i = threadIdx.x; i < TL_NB; i += TL_THREADS) h[i] = 0;
+  __syncthreads();
+  const size_t k0 = (size_t)blockIdx.x * CH, k1 = k0 + CH < m ? k0 + CH : m;
+  for (size_t k = k0 + threadIdx.x; k < k1; k += TL_THREADS) {
+    double v[DIM];
+    tl_load<DIM>(y, k, ytda, v);
+    atomicAdd(&h[tl_cell<DIM>(t, v) >> shift], 1u);
+  }
+  __syncthreads();
+  for (unsigned b = threadIdx.x; b < nb; b += TL_THREADS) cnt[(size_t)b * nwg + blockIdx.x] = h[b];
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(TL_THREADS)
+tl_coarse_scatter_kernel(const double *__restrict__ y, size_t m, size_t ytda, const TlGrid *__restrict__ grid, int shift, unsigned nb,
+                         unsigned nwg, const unsigned *__restrict__ cnt, double *__restrict__ t_y, unsigned *__restrict__ pos1)
+{
+  constexpr int CH = TlGeom<DIM>::CH, PT = CH / TL_THREADS;
+  extern __shared__ __attribute__((aligned(16))) double tl_lds[];
+  double *ly = tl_lds;                                              /* [CH][DIM] the chunk in bin order */
+  unsigned *ldest = (unsigned *)(ly + (size_t)CH * DIM);            /* [CH] destination of every LDS slot */
+  __shared__ unsigned lh[TL_NB], gbase[TL_NB], s_w[8];
+  const TlGrid t = *grid;
+  for (unsigned b = threadIdx.x; b < TL_NB; b += TL_THREADS) { lh[b] = 0; gbase[b] = b < nb ? cnt[(size_t)b * nwg + blockIdx.x] : 0u; }
+  __syncthreads();
+  const size_t k0 = (size_t)blockIdx.x * CH, k1 = k0 + CH < m ? k0 + CH : m;
+  double v[PT][DIM];
+  unsigned bb[PT], rr[PT];
+#pragma unroll
+  for (int i = 0; i < PT; i++) {
+    const size_t k = k0 + (size_t)i * TL_THREADS + threadIdx.x;
+    if (k < k1) {
+      tl_load<DIM>(y, k, ytda, v[i]);
+      bb[i] = tl_cell<DIM>(t, v[i]) >> shift;
+      rr[i] = atomicAdd(&lh[bb[i]], 1u);
+    }
+  }
+  __syncthreads();
+  tl_block_scan(lh, TL_NB, s_w);                                    /* lh: first LDS slot of every bin */
+#pragma unroll
+  for (int i = 0; i < PT; i++) {
+    const size_t k = k0 + (size_t)i * TL_THREADS + threadIdx.x;
+    if (k < k1) {
+      const unsigned lp = lh[bb[i]] + rr[i], dest = gbase[bb[i]] + rr[i];
+#pragma unroll
+      for (int c = 0; c < DIM; c++) ly[(size_t)lp * DIM + c] = v[i][c];
+      ldest[lp] = dest;
+      pos1[k] = dest;
+    }
+  }
+  __syncthreads();
+  const unsigned nloc = (unsigned)(k1 - k0);
+  for (unsigned sl = threadIdx.x; sl < nloc; sl += TL_THREADS) {
+    const size_t d = ldest[sl];
+    if (DIM == 2) *reinterpret_cast<double2 *>(t_y + d * 2) = *reinterpret_cast<const double2 *>(ly + (size_t)sl * 2);
+    else {
+#pragma unroll
+      for (int c = 0; c < DIM; c++) t_y[d * DIM + c] = ly[(size_t)sl * DIM + c];
+    }
+  }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(TL_THREADS)
+tl_fine_hist_kernel(const double *__restrict__ t_y, size_t m, const TlGrid *__restrict__ grid, int shift, unsigned *__restrict__ count,
+                    unsigned *__restrict__ ubase, unsigned *__restrict__ fin)
+{
+  constexpr int P = TlGeom<DIM>::P;
+  __shared__ unsigned h[TL_W];
+  const TlGrid t = *grid;
+  for (int i = threadIdx.x; i < TL_W; i += TL_THREADS) h[i] = 0;
+  __syncthreads();
+  const size_t i0 = (size_t)blockIdx.x * P, i1 = i0 + P < m ? i0 + P : m;
+  double v0[DIM];
+  tl_load<DIM, true>(t_y, i0, DIM, v0);
+  const unsigned c_first = (tl_cell<DIM>(t, v0) >> shift) << shift;   /* bins ascend along p1: no cell of the unit is below its first point's bin */
+  for (size_t i = i0 + threadIdx.x; i < i1; i += TL_THREADS) {
+    double v[DIM];
+    tl_load<DIM, true>(t_y, i, DIM, v);
+    const unsigned c = tl_cell<DIM>(t, v), d = c - c_first;
     if (d < TL_W) atomicAdd(&h[d], 1u);
     else fin[i] = atomicAdd(&count[c], 1u);
   }
   __syncthreads();
-  for (unsigned d = threadIdx.x; d < TL_W; d += 256)
+  for (unsigned d = threadIdx.x; d < TL_W; d += TL_THREADS)
     if (h[d]) ubase[(size_t)blockIdx.x * TL_W + d] = atomicAdd(&count[c_first + d], h[d]);
 }
 
 template <int DIM>
-__global__ void __launch_bounds__(256)
-tl_fine_scatter_kernel(const double *__restrict__ t_y, const unsigned *__restrict__ t_c, size_t m, int shift,
-                       const unsigned *__restrict__ offset, const unsigned *__restrict__ ubase, unsigned *__restrict__ fin,
-                       double *__restrict__ ys)
+__global__ void __launch_bounds__(TL_THREADS)
+tl_fine_scatter_kernel(const double *__restrict__ t_y, size_t m, const TlGrid *__restrict__ grid, int shift, unsigned ncell,
+                       const unsigned *__restrict__ offset, const unsigned *__restrict__ ubase, const unsigned *__restrict__ fin,
+                       double *__restrict__ ys, unsigned *__restrict__ inv)
 {
-  __shared__ unsigned ub[TL_W], cur[TL_W];
-  for (unsigned d = threadIdx.x; d < TL_W; d += 256) { ub[d] = ubase[(size_t)blockIdx.x * TL_W + d]; cur[d] = 0; }   /* unused entries: never read */
+  constexpr int P = TlGeom<DIM>::P, PT = P / TL_THREADS;
+  extern __shared__ __attribute__((aligned(16))) double tl_lds[];
+  double *ly = tl_lds;                                              /* [P][DIM] the unit in cell order, the out-of-window points at the tail */
+  unsigned *ldest = (unsigned *)(ly + (size_t)P * DIM);             /* [P] position in cell order */
+  unsigned *lsrc = ldest + P;                                       /* [P] position in the coarse order */
+  unsigned *lcnt = lsrc + P;                                        /* [TL_W] counts, then first LDS slot of every cell */
+  unsigned *ub = lcnt + TL_W;                                       /* [TL_W] offset[cell] + the unit's share of the cell (C1) */
+  __shared__ unsigned s_w[8], s_tail;
+  const TlGrid t = *grid;
+  const size_t i0 = (size_t)blockIdx.x * P, i1 = i0 + P < m ? i0 + P : m;
+  double v0[DIM];
+  tl_load<DIM, true>(t_y, i0, DIM, v0);
+  const unsigned c_first = (tl_cell<DIM>(t, v0) >> shift) << shift;
+  /* (entries of cells the unit does not hold are never read: ubase is undefined there, offset may lie past the table) */
+  for (unsigned d = threadIdx.x; d < TL_W; d += TL_THREADS) {
+    lcnt[d] = 0;
+    ub[d] = (c_first + d < ncell ? offset[c_first + d] : 0u) + ubase[(size_t)blockIdx.x * TL_W + d];
+  }
+  if (threadIdx.x == 0) s_tail = 0;
   __syncthreads();
-  const size_t i0 = (size_t)blockIdx.x * TL_P, i1 = i0 + TL_P < m ? i0 + TL_P : m;
-  const unsigned c_first = (t_c[i0] >> shift) << shift;
-  for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
-    const unsigned c = t_c[i], d = c - c_first;
-    const unsigned p = offset[c] + (d < TL_W ? ub[d] + atomicAdd(&cur[d], 1u) : fin[i]);
-    if (DIM == 2) *reinterpret_cast<double2 *>(ys + (size_t)p * 2) = *reinterpret_cast<const double2 *>(t_y + i * 2);
-    else
-      for (int q = 0; q < DIM; q++) ys[(size_t)p * DIM + q] = t_y[i * DIM + q];
-    fin[i] = p;
+  double v[PT][DIM];
+  unsigned cc[PT], rr[PT];
+#pragma unroll
+  for (int q = 0; q < PT; q++) {
+    const size_t i = i0 + (size_t)q * TL_THREADS + threadIdx.x;
+    if (i < i1) {
+      tl_load<DIM, true>(t_y, i, DIM, v[q]);
+      cc[q] = tl_cell<DIM>(t, v[q]);
+      const unsigned d = cc[q] - c_first;
+      rr[q] = d < TL_W ? atomicAdd(&lcnt[d], 1u) : atomicAdd(&s_tail, 1u);
+    }
+  }
+  __syncthreads();
+  const unsigned nwin = tl_block_scan(lcnt, TL_W, s_w);
+#pragma unroll
+  for (int q = 0; q < PT; q++) {
+    const size_t i = i0 + (size_t)q * TL_THREADS + threadIdx.x;
+    if (i < i1) {
+      const unsigned d = cc[q] - c_first;
+      const unsigned lp = d < TL_W ? lcnt[d] + rr[q] : nwin + rr[q];
+      const unsigned dest = d < TL_W ? ub[d] + rr[q] : offset[cc[q]] + fin[i];
+#pragma unroll
+      for (int c = 0; c < DIM; c++) ly[(size_t)lp * DIM + c] = v[q][c];
+      ldest[lp] = dest;
+      lsrc[lp] = (unsigned)i;
+    }
+  }
+  __syncthreads();
+  const unsigned nloc = (unsigned)(i1 - i0);
+  for (unsigned sl = threadIdx.x; sl < nloc; sl += TL_THREADS) {
+    const size_t d = ldest[sl];
+    if (DIM == 2) *reinterpret_cast<double2 *>(ys + d * 2) = *reinterpret_cast<const double2 *>(ly + (size_t)sl * 2);
+    else {
+#pragma unroll
+      for (int c = 0; c < DIM; c++) ys[d * DIM + c] = ly[(size_t)sl * DIM + c];
+    }
+    inv[d] = lsrc[sl];
   }
 }
 
-/* un-sort, first hop: results from cell order back to the coarse order (a gather inside the unit's window) */
-template <int PACKED>
-__global__ void __launch_bounds__(256)
-tl_unsort_local_kernel(const unsigned *__restrict__ fin, size_t m, const double *__restrict__ vs, const int *__restrict__ ls,
-                       double *__restrict__ res)
-{
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    const size_t p = fin[i];
-    if (PACKED == 1) reinterpret_cast<double2 *>(res)[i] = reinterpret_cast<const double2 *>(vs)[p];
-    else if (PACKED == 2) reinterpret_cast<double2 *>(res)[i] = make_double2(vs[p], __longlong_as_double((long long)ls[p]));
-    else res[i] = vs[p];
-  }
-}
-
-/* second hop: the one random gather, 16 (8) bytes per target */
+/* the one random gather of the two-level scheme: 16 (8) bytes per target from the results in the coarse order */
 template <int PACKED>
 __global__ void __launch_bounds__(256)
 tl_unsort_final_kernel(const unsigned *__restrict__ pos1, size_t m, const double *__restrict__ res, double *__restrict__ values,
@@ -478,8 +614,36 @@ tl_unsort_final_kernel(const unsigned *__restrict__ pos1, size_t m, const double
 
 static bool sort_two_level(size_t m)
 {
-  const char *e = getenv("GSL_SINTERP_SORT_TWO_LEVEL");      /* opt-in; read per call: the tests compare both routes in one process */
-  return e && e[0] == '1' && m >= TL_MIN_M;
+  const char *e = getenv("GSL_SINTERP_SORT_LEVELS");         /* developer override "1" / "2"; read per call: the tests compare both routes */
+  const bool two = e && (e[0] == '1' || e[0] == '2') ? e[0] == '2' : true;
+  return two && m >= TL_MIN_M;
+}
+
+bool sinterp_sort_reorder_is_two_level(size_t m) { return sort_two_level(m); }
+
+template <int DIM>
+static int tl_launch(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, size_t ncell, const TlGrid *grid, double *t_y,
+                     unsigned *cnt, unsigned *ubase, sinterp_sorted *out)
+{
+  constexpr int CH = TlGeom<DIM>::CH, P = TlGeom<DIM>::P;
+  int shift = 0;
+  while (((ncell - 1) >> shift) >= TL_NB) shift++;
+  const unsigned nb = (unsigned)((ncell - 1) >> shift) + 1u, nwg = (unsigned)((m + CH - 1) / CH), nu = (unsigned)((m + P - 1) / P);
+  const size_t nc = (size_t)nb * nwg;
+  const size_t lds_b = (size_t)CH * DIM * 8 + (size_t)CH * 4, lds_c = (size_t)P * DIM * 8 + (size_t)P * 8 + (size_t)TL_W * 8;
+  { int ast = sinterp_func_lds(ctx, (const void *)tl_coarse_scatter_kernel<DIM>, (int)lds_b); if (ast) return ast; }
+  { int ast = sinterp_func_lds(ctx, (const void *)tl_fine_scatter_kernel<DIM>, (int)lds_c); if (ast) return ast; }
+  hipLaunchKernelGGL((tl_coarse_hist_kernel<DIM>), dim3(nwg), dim3(TL_THREADS), 0, ctx->stream, d_y, m, ytda, grid, shift, nb, nwg, cnt);
+  launch_cell_scan(ctx, cnt, nc, cnt + nc + 1);
+  hipLaunchKernelGGL((tl_coarse_scatter_kernel<DIM>), dim3(nwg), dim3(TL_THREADS), lds_b, ctx->stream, d_y, m, ytda, grid, shift, nb, nwg,
+                     (const unsigned *)cnt, t_y, out->slot);
+  hipLaunchKernelGGL((tl_fine_hist_kernel<DIM>), dim3(nu), dim3(TL_THREADS), 0, ctx->stream, (const double *)t_y, m, grid, shift, out->offset,
+                     ubase, out->fin);
+  launch_cell_scan(ctx, out->offset, ncell, out->offset + ncell + 1);
+  hipLaunchKernelGGL((tl_fine_scatter_kernel<DIM>), dim3(nu), dim3(TL_THREADS), lds_c, ctx->stream, (const double *)t_y, m, grid, shift,
+                     (unsigned)ncell, (const unsigned *)out->offset, (const unsigned *)ubase, (const unsigned *)out->fin, out->ys, out->inv);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
 }
 
 /* m_cap >= m sizes the buffer section (two sections -- `slot` 0 / 1 -- so that two chunks of one batch can be in
@@ -505,18 +669,19 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
     for (int c = 0; c < dim; c++) ncell_cap *= (size_t)gc;
     if (ncell_cap < ncell) ncell_cap = ncell;
   }
-  /* layout: box | ys | vs | ls | cellid | slot | count(+1) [| t_y | t_c | fin | cnt | ubase : two-level] ; every section
+  /* layout: box | ys | vs | ls | cellid | slot | count(+1) [| t_y (later res1) | inv | fin | cnt | ubase | grid : two-level] ; every section
      16-byte aligned */
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
   const bool two = sort_two_level(m_cap) && dim >= 1 && dim <= 3;
-  const size_t nwg_cap = (m_cap + TL_CH - 1) / TL_CH, nu_cap = (m_cap + TL_P - 1) / TL_P;
+  const size_t tl_ch = dim == 3 ? TlGeom<3>::CH : TlGeom<2>::CH, tl_p = TlGeom<2>::P;
+  const size_t nwg_cap = (m_cap + tl_ch - 1) / tl_ch, nu_cap = (m_cap + tl_p - 1) / tl_p;
   const size_t cnt_n = (size_t)TL_NB * nwg_cap;
   const size_t o_ys = 64, o_vs = o_ys + up(m_cap * dim * 8), o_ls = o_vs + up(m_cap * 16), o_cell = o_ls + up(m_cap * 4),
                o_slot = o_cell + up(m_cap * 4), o_cnt = o_slot + up(m_cap * 4),
                o_ty = o_cnt + up((ncell_cap + 1) * 4 + (ncell_cap / 1024 + 8) * 4),
-               o_tc = o_ty + (two ? up(m_cap * (dim * 8 > 16 ? dim * 8 : 16)) : 0), o_fin = o_tc + (two ? up(m_cap * 4) : 0),
+               o_inv = o_ty + (two ? up(m_cap * (dim * 8 > 16 ? dim * 8 : 16)) : 0), o_fin = o_inv + (two ? up(m_cap * 4) : 0),
                o_ca = o_fin + (two ? up(m_cap * 4) : 0), o_ub = o_ca + (two ? up((cnt_n + 1) * 4 + (cnt_n / 1024 + 8) * 4) : 0),
-               bytes = (o_ub + (two ? up(nu_cap * TL_W * 4) : 0) + 255) & ~(size_t)255;
+               o_grid = o_ub + (two ? up(nu_cap * TL_W * 4) : 0), bytes = (o_grid + (two ? 64 : 0) + 255) & ~(size_t)255;
   void *buf = NULL;
   int st = sinterp_sortbuf(ctx, bytes * (slot >= 0 ? 2 : 1), &buf);
   if (st) return st;
@@ -525,7 +690,7 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   out->ys = (double *)(b + o_ys); out->vs = (double *)(b + o_vs); out->ls = (int *)(b + o_ls);
   out->cellid = (unsigned *)(b + o_cell); out->slot = (unsigned *)(b + o_slot); out->offset = (unsigned *)(b + o_cnt);
   out->two_level = two && m >= TL_MIN_M;
-  out->fin = (unsigned *)(b + o_fin); out->res1 = (double *)(b + o_ty);
+  out->fin = (unsigned *)(b + o_fin); out->res1 = (double *)(b + o_ty); out->inv = (unsigned *)(b + o_inv);
   HIP_OK(ctx, hipMemsetAsync(out->offset, 0, ncell * 4, ctx->stream));
   size_t blocks = (m + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -536,36 +701,13 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
     box = out->box;
   } else out->box = (unsigned long long *)box_in;
   if (out->two_level) {
-    int shift = 0;
-    while (((ncell - 1) >> shift) >= TL_NB) shift++;
-    const unsigned nb = (unsigned)((ncell - 1) >> shift) + 1u, nwg = (unsigned)((m + TL_CH - 1) / TL_CH), nu = (unsigned)((m + TL_P - 1) / TL_P);
+    TlGrid *grid = (TlGrid *)(b + o_grid);
     double *t_y = (double *)(b + o_ty);
-    unsigned *t_c = (unsigned *)(b + o_tc), *cnt = (unsigned *)(b + o_ca), *ubase = (unsigned *)(b + o_ub);
-    const size_t nc = (size_t)nb * nwg;
-    hipLaunchKernelGGL(tl_coarse_hist_kernel, dim3(nwg), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g, box, shift, nb, nwg, out->cellid, cnt);
-    launch_cell_scan(ctx, cnt, nc, cnt + nc + 1);
-    if (dim == 2)
-      hipLaunchKernelGGL(tl_coarse_scatter_kernel<2>, dim3(nwg), dim3(256), 0, ctx->stream, d_y, m, ytda, (const unsigned *)out->cellid, shift, nb,
-                         nwg, (const unsigned *)cnt, t_y, t_c, out->slot);
-    else if (dim == 3)
-      hipLaunchKernelGGL(tl_coarse_scatter_kernel<3>, dim3(nwg), dim3(256), 0, ctx->stream, d_y, m, ytda, (const unsigned *)out->cellid, shift, nb,
-                         nwg, (const unsigned *)cnt, t_y, t_c, out->slot);
-    else
-      hipLaunchKernelGGL(tl_coarse_scatter_kernel<1>, dim3(nwg), dim3(256), 0, ctx->stream, d_y, m, ytda, (const unsigned *)out->cellid, shift, nb,
-                         nwg, (const unsigned *)cnt, t_y, t_c, out->slot);
-    hipLaunchKernelGGL(tl_fine_hist_kernel, dim3(nu), dim3(256), 0, ctx->stream, (const unsigned *)t_c, m, shift, out->offset, ubase, out->fin);
-    launch_cell_scan(ctx, out->offset, ncell, out->offset + ncell + 1);
-    if (dim == 2)
-      hipLaunchKernelGGL(tl_fine_scatter_kernel<2>, dim3(nu), dim3(256), 0, ctx->stream, (const double *)t_y, (const unsigned *)t_c, m, shift,
-                         (const unsigned *)out->offset, (const unsigned *)ubase, out->fin, out->ys);
-    else if (dim == 3)
-      hipLaunchKernelGGL(tl_fine_scatter_kernel<3>, dim3(nu), dim3(256), 0, ctx->stream, (const double *)t_y, (const unsigned *)t_c, m, shift,
-                         (const unsigned *)out->offset, (const unsigned *)ubase, out->fin, out->ys);
-    else
-      hipLaunchKernelGGL(tl_fine_scatter_kernel<1>, dim3(nu), dim3(256), 0, ctx->stream, (const double *)t_y, (const unsigned *)t_c, m, shift,
-                         (const unsigned *)out->offset, (const unsigned *)ubase, out->fin, out->ys);
-    LAUNCH_CHECK(ctx);
-    return ST_SUCCESS;
+    unsigned *cnt = (unsigned *)(b + o_ca), *ubase = (unsigned *)(b + o_ub);
+    hipLaunchKernelGGL(tl_grid_kernel, dim3(1), dim3(64), 0, ctx->stream, box, dim, g, grid);
+    if (dim == 2) return tl_launch<2>(ctx, d_y, m, ytda, ncell, grid, t_y, cnt, ubase, out);
+    if (dim == 3) return tl_launch<3>(ctx, d_y, m, ytda, ncell, grid, t_y, cnt, ubase, out);
+    return tl_launch<1>(ctx, d_y, m, ytda, ncell, grid, t_y, cnt, ubase, out);
   }
   hipLaunchKernelGGL(cell_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_y, m, ytda, dim, g,
                      box, out->cellid, out->slot, out->offset);
@@ -594,9 +736,7 @@ int sinterp_unsort_packed(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, siz
   if (m == 0) return ST_SUCCESS;
   size_t blocks = (m + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (s->two_level) {
-    hipLaunchKernelGGL(tl_unsort_local_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->fin, m,
-                       (const double *)s->vs, (const int *)NULL, s->res1);
+  if (s->two_level) {                            /* the sweep stored {value, leaf} pairs at res1[inv[p]] */
     hipLaunchKernelGGL(tl_unsort_final_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
                        (const double *)s->res1, d_values, d_leaf);
     LAUNCH_CHECK(ctx);
@@ -613,18 +753,10 @@ int sinterp_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, 
   if (m == 0 || (!d_values && !d_leaf)) return ST_SUCCESS;
   size_t blocks = (m + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (s->two_level) {
-    if (d_leaf) {
-      hipLaunchKernelGGL(tl_unsort_local_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->fin, m,
-                         (const double *)s->vs, (const int *)s->ls, s->res1);
-      hipLaunchKernelGGL(tl_unsort_final_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
-                         (const double *)s->res1, d_values, d_leaf);
-    } else {
-      hipLaunchKernelGGL(tl_unsort_local_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->fin, m,
-                         (const double *)s->vs, (const int *)NULL, s->res1);
-      hipLaunchKernelGGL(tl_unsort_final_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
-                         (const double *)s->res1, d_values, (int *)NULL);
-    }
+  if (s->two_level) {                            /* the sweep stored plain values at res1[inv[p]] */
+    if (d_leaf) return sinterp_fail(ctx, ST_EINVAL, "unsort: leaf output of a two-level reorder is packed", hipSuccess, __FILE__, __LINE__);
+    hipLaunchKernelGGL(tl_unsort_final_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
+                       (const double *)s->res1, d_values, (int *)NULL);
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }

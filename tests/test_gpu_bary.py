@@ -385,9 +385,9 @@ def test_chunked_two_stream_pipeline_changes_no_bit(pkg, orc, monkeypatch):
 
 @pytest.mark.parametrize("shape", ["uniform", "cluster_plus_sparse_background"])
 def test_two_level_reorder_matches_one_level_and_oracle(pkg, orc, monkeypatch, shape):
-    """Round 3 (opt-in until it is the faster one): batches of >= 2^18 targets can be ordered by the two-level reorder of sort.hip (coarse bins by LDS
-    histograms, cells inside LDS windows, one global atomic per occupied (unit, cell)) when GSL_SINTERP_SORT_TWO_LEVEL=1;
-    the default is the one-atomic-per-point route.  A value depends on (records, target) only, so both routes must return the
+    """Round 3: batches of >= 2^18 targets are ordered by the two-level reorder of sort.hip (coarse bins by LDS
+    histograms, cells inside LDS windows, one global atomic per occupied (unit, cell), every scattered store staged through
+    LDS into runs); GSL_SINTERP_SORT_LEVELS=1 / 2 forces the one-atomic-per-point route / this one.  A value depends on (records, target) only, so both routes must return the
     oracle's bits at every position.  `cluster_plus_sparse_background`: 95 % of the targets in a small disc stretch the
     grid so that the remaining 5 % leave < 4 points per cell -- units that span more cells than their LDS window and take
     the per-point fallback for the cells beyond it.  Also the values-only un-sort (8-byte results, no leaf)."""
@@ -408,15 +408,16 @@ def test_two_level_reorder_matches_one_level_and_oracle(pkg, orc, monkeypatch, s
     t, o = build_pair(pkg, orc, x)
     d = t.device_alloc(0)
     assert d.set_response(f) == 0
+    monkeypatch.setenv("GSL_SINTERP_SORT_LEVELS", "1")
     st1, v1, l1 = d.eval_many(y)
-    monkeypatch.setenv("GSL_SINTERP_SORT_TWO_LEVEL", "1")
+    monkeypatch.setenv("GSL_SINTERP_SORT_LEVELS", "2")
     st2, v2, l2 = d.eval_many(y)
     ty = dev(y)
     tv = torch.full((m,), -3.0, dtype=torch.float64, device="cuda")
     assert d.eval_resident(ptr(ty), m, 2, ptr(tv), None) == st2          # values only
     torch.cuda.synchronize()
     assert np.array_equal(bits(tv.cpu().numpy()), bits(v2))
-    monkeypatch.delenv("GSL_SINTERP_SORT_TWO_LEVEL")
+    monkeypatch.delenv("GSL_SINTERP_SORT_LEVELS")
     assert st1 == st2
     assert np.array_equal(l1, l2) and np.array_equal(bits(v1), bits(v2))
     idx = np.unique(np.concatenate([np.arange(0, m, 41), np.arange(m - 3000, m)]))

@@ -374,3 +374,36 @@ def test_model_cached_sweep_equals_uncached(pkg, orc):
     want2 = orc.rbf_eval(0, eps, x, w2, y)
     assert relerr(sweep(12), want2) < TOL
     assert relerr(sweep(0), want2) < TOL
+
+
+@pytest.mark.parametrize("kind,dim,n", [(0, 2, 3000), (0, 3, 2500), (2, 2, 3000), (0, 1, 1500)])
+def test_large_batch_reorder_route_returns_the_bits_of_the_permutation_route(pkg, orc, monkeypatch, kind, dim, n):
+    """Round 3: batches of >= 2^18 targets of the local kernels are physically put in cell order by the two-level reorder
+    (sort.hip), swept contiguously, stored through the order's map and gathered back; smaller batches (and
+    GSL_SINTERP_SORT_LEVELS=1) keep the permutation route.  A target's value depends on the model and the target only:
+    both routes must agree bit for bit, strided targets (ytda > dim), NaN and far targets included; a sample against
+    the oracle's naive sums."""
+    m, ytda = 300_000, dim + 2
+    x = orc.synth_centres(n, dim)
+    eps = orc.gaussian_eps(n, dim) if kind == 0 else 0.25
+    rng = np.random.default_rng(n + dim)
+    w = rng.standard_normal(n)
+    wide = np.full((m, ytda), 1e30)
+    wide[:, :dim] = rng.random((m, dim))
+    wide[-40:, :dim] += 40.0
+    wide[1234, 0] = np.nan
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_x, d_w, d_y = dev(x), dev(w), dev(wide)
+    out = {}
+    for levels in ("1", "2"):
+        monkeypatch.setenv("GSL_SINTERP_SORT_LEVELS", levels)
+        d_s = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
+        assert ctx.rbf_eval(kind, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), m, ytda, ptr(d_s)) == 0
+        ctx.sync()
+        out[levels] = d_s.cpu().numpy()
+    monkeypatch.delenv("GSL_SINTERP_SORT_LEVELS")
+    assert np.array_equal(bits(out["1"]), bits(out["2"]))
+    assert np.isnan(out["2"][1234]) and (out["2"][-40:] == 0.0).all()
+    idx = np.setdiff1d(np.arange(0, m, 131), [1234])
+    want = orc.rbf_eval(kind, eps, x, w, np.ascontiguousarray(wide[idx, :dim]))
+    assert relerr(out["2"][idx], want) < TOL
