@@ -385,7 +385,7 @@ def test_large_batch_reorder_route_returns_the_bits_of_the_permutation_route(pkg
     the oracle's naive sums."""
     m, ytda = 300_000, dim + 2
     x = orc.synth_centres(n, dim)
-    eps = orc.gaussian_eps(n, dim) if kind == 0 else 0.25
+    eps = orc.gaussian_eps(n, dim) if kind == 0 else 0.125 * n ** (1.0 / dim)   # Wendland: support radius 1 / eps
     rng = np.random.default_rng(n + dim)
     w = rng.standard_normal(n)
     wide = np.full((m, ytda), 1e30)
