@@ -398,7 +398,7 @@ def test_large_batch_reorder_route_returns_the_bits_of_the_permutation_route(pkg
     for levels in ("1", "2"):
         monkeypatch.setenv("GSL_SINTERP_SORT_LEVELS", levels)
         d_s = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
-        assert ctx.rbf_eval(kind, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), m, ytda, ptr(d_s)) == 0
+        ctx.rbf_eval(kind, eps, ptr(d_x), n, dim, dim, ptr(d_w), ptr(d_y), m, ytda, ptr(d_s))
         ctx.sync()
         out[levels] = d_s.cpu().numpy()
     monkeypatch.delenv("GSL_SINTERP_SORT_LEVELS")
