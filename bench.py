@@ -38,7 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix = vector peak; 256 CU x 128 flop/clk x 2.4 GHz
 VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9   # fp64 VALU issue: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz lane-instructions/s
-PMC_ROUND = "r02"            # committed rocprofv3 --pmc passes the static counter figures are read from
+PMC_ROUND = "r03"            # committed rocprofv3 --pmc passes the static counter figures are read from
 
 CONFIGS = {
     # name: (kind, dim, n_centres, m_targets, sharding)   sharding: per_gpu = weak, total = strong
@@ -392,10 +392,10 @@ def rooflines(cfg, name, n, dim, m_rank, ph, extra=None, gemm=None):
                            "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 6),
                            "traffic": pmc["hbm_traffic_bytes_per_launch"] if pmc and "hbm_traffic_bytes_per_launch" in pmc else None,
                            "traffic_source": pmc["source"] if pmc else None,
-                           "note": "the algorithmic HBM stream is 28 B/target; about half of the step is the cell sort of the "
-                                   "targets (one returning atomic per target) and the un-sort gather, the other half the DAG "
-                                   "walk, which is bound by the latency of its dependent 64-byte gathers (records resident in "
-                                   "L2 / Infinity Cache), not by HBM"}
+                           "note": "the algorithmic HBM stream is 28 B/target; a third of the step is the two-level reorder of the "
+                                   "targets (five streaming passes, 104 B/target at ~3.3 TB/s) and the one random gather of the "
+                                   "un-sort, the rest the DAG walk, which is bound by the latency of its dependent 64-byte "
+                                   "gathers (records resident in L2 / Infinity Cache), not by HBM"}
         res["eval_only_mpts"] = round(m_rank / t / 1e6, 3)
         return res
     route = (extra or {}).get("route", {}).get("route", 1)

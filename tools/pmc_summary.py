@@ -18,7 +18,7 @@ expects gpurun_out/pmc/<CONFIG>_<COUNTER>/**/*counter_collection.csv.  Writes
 import collections, csv, glob, json, os, re, sys
 
 root = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 vals = collections.defaultdict(lambda: collections.defaultdict(list))     # (cfg, kernel) -> counter -> [values per dispatch]
 for d in sorted(glob.glob(os.path.join(root, "*_*"))):
     m = re.match(r"(C\d)_([A-Z0-9_]+)$", os.path.basename(d))
@@ -34,7 +34,7 @@ for d in sorted(glob.glob(os.path.join(root, "*_*"))):
             vals[(cfg, name)][ctr].append(float(r["Counter_Value"]))
 
 KEEP = ("gemm_minus_streamk_kernel", "rbf_eval", "bary_eval_kernel", "bary_walk_kernel", "bary_start_kernel", "bary_finish_kernel", "walk_pack_kernel", "rbf_fill_kernel", "trsv_dataflow_kernel", "chol_trsm128_kernel",
-        "chol_diag128_kernel", "cell_", "tree_", "unsort_", "jump_build_kernel", "centre_pack_kernel")
+        "chol_diag128_kernel", "cell_", "tl_", "tree_", "unsort_", "jump_build_kernel", "centre_pack_kernel")
 counters = collections.defaultdict(dict)
 rows, traffic = [], collections.defaultdict(dict)
 for (cfg, name), c in sorted(vals.items()):
