@@ -184,6 +184,7 @@ struct sinterp_sorted {
   unsigned *inv;                /*   inv[p] = coarse position of the target at cell-order position p: the sweep stores the result of */
   double *res1;                 /*   sorted target p at res1[inv[p]] (8 bytes, or a {value, leaf} pair), NOT at vs[p]; */
   unsigned *fin;                /*   (internal: slots of the out-of-window points between the two fine passes) */
+  unsigned *tl_cnt; unsigned tl_nb, tl_nwg, tl_ch;   /* (internal: first coarse position of every (bin, workgroup) run, for the staged un-sort) */
 };
 int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size_t ytda, int dim, int per_cell,
                          sinterp_sorted *out, size_t m_cap, int slot, const unsigned long long *box_in);

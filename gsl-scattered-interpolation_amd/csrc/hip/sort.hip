@@ -633,6 +633,50 @@ tl_unsort_final_kernel(const unsigned *__restrict__ pos1, size_t m, const double
   }
 }
 
+/* The same gather staged through LDS: workgroup w of the coarse scatter wrote its chunk as <= TL_NB runs, one per bin, at
+   positions [run[b], run[b] + len[b]) of the coarse order (run = the scanned cnt[bin][workgroup] matrix, len = the
+   difference to the next entry).  The runs are copied into LDS with consecutive lanes on consecutive positions, then
+   target k reads its result from the LDS image (bin of pos1[k] by binary search in run[]): the global side of the un-sort is
+   sequential.  ESZ: doubles per result (1: value, 2: {value, leaf}). */
+template <int ESZ, int CH>
+__global__ void __launch_bounds__(TL_THREADS)
+tl_unsort_staged_kernel(const unsigned *__restrict__ pos1, size_t m, const unsigned *__restrict__ cnt, unsigned nb, unsigned nwg,
+                        const double *__restrict__ res, double *__restrict__ values, int *__restrict__ leaf)
+{
+  extern __shared__ __attribute__((aligned(16))) double tl_lds[];
+  double *lres = tl_lds;                                            /* [CH][ESZ] */
+  __shared__ unsigned run[TL_NB], lstart[TL_NB + 1], s_w[8];
+  for (unsigned b = threadIdx.x; b < TL_NB; b += TL_THREADS) {
+    unsigned r = 0, len = 0;
+    if (b < nb) { const size_t idx = (size_t)b * nwg + blockIdx.x; r = cnt[idx]; len = cnt[idx + 1] - r; }
+    run[b] = r; lstart[b] = len;
+  }
+  __syncthreads();
+  const unsigned nloc = tl_block_scan(lstart, TL_NB, s_w);          /* lstart: first LDS slot of every run */
+  if (threadIdx.x == 0) lstart[TL_NB] = nloc;
+  __syncthreads();
+  for (unsigned sl = threadIdx.x; sl < nloc; sl += TL_THREADS) {
+    unsigned lo = 0, hi = nb;                                       /* largest b with lstart[b] <= sl (empty runs share a start: take the last) */
+    while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (lstart[mid] <= sl) lo = mid; else hi = mid; }
+    const size_t src = (size_t)run[lo] + (sl - lstart[lo]);
+    if (ESZ == 2) reinterpret_cast<double2 *>(lres)[sl] = reinterpret_cast<const double2 *>(res)[src];
+    else lres[sl] = res[src];
+  }
+  __syncthreads();
+  const size_t k0 = (size_t)blockIdx.x * CH, k1 = k0 + CH < m ? k0 + CH : m;
+  for (size_t k = k0 + threadIdx.x; k < k1; k += TL_THREADS) {
+    const unsigned p = pos1[k];
+    unsigned lo = 0, hi = nb;                                       /* the run that holds p: the largest b with run[b] <= p (runs of later bins start past p) */
+    while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (run[mid] <= p) lo = mid; else hi = mid; }
+    const unsigned sl = lstart[lo] + (p - run[lo]);
+    if (ESZ == 2) {
+      const double2 r = reinterpret_cast<const double2 *>(lres)[sl];
+      if (values) values[k] = r.x;
+      if (leaf) leaf[k] = (int)__double_as_longlong(r.y);
+    } else values[k] = lres[sl];
+  }
+}
+
 static bool sort_two_level(size_t m)
 {
   const char *e = getenv("GSL_SINTERP_SORT_LEVELS");         /* developer override "1" / "2"; read per call: the tests compare both routes */
@@ -663,6 +707,37 @@ static int tl_launch(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, size
   launch_cell_scan(ctx, out->offset, ncell, out->offset + ncell + 1);
   hipLaunchKernelGGL((tl_fine_scatter_kernel<DIM>), dim3(nu), dim3(TL_THREADS), lds_c, ctx->stream, (const double *)t_y, m, grid, shift,
                      (unsigned)ncell, (const unsigned *)out->offset, (const unsigned *)ubase, (const unsigned *)out->fin, out->ys, out->inv);
+  out->tl_cnt = cnt; out->tl_nb = nb; out->tl_nwg = nwg; out->tl_ch = (unsigned)CH;
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+/* un-sort of a two-level order: ESZ doubles per result */
+template <int ESZ>
+static int tl_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, double *d_values, int *d_leaf)
+{
+  /* measured at M = 10^7: 8-byte results 85 us staged against ~100 us for the plain gather (three workgroups per CU);
+     16-byte {value, leaf} pairs 200 us staged against 130 us (98 KB of LDS: one workgroup per CU, nothing hides the table
+     loads and the searches) -- the pairs keep the plain gather.  GSL_SINTERP_UNSORT_GATHER=1 (developer): plain gather always */
+  static const bool unstaged = getenv("GSL_SINTERP_UNSORT_GATHER") && getenv("GSL_SINTERP_UNSORT_GATHER")[0] == '1';
+  if (unstaged || !s->tl_cnt || ESZ == 2) {
+    size_t blocks = (m + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((tl_unsort_final_kernel<ESZ == 2>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
+                       (const double *)s->res1, d_values, d_leaf);
+  } else if (s->tl_ch == (unsigned)TlGeom<2>::CH) {
+    constexpr int CH = TlGeom<2>::CH;
+    const size_t lds = (size_t)CH * ESZ * 8;
+    { int ast = sinterp_func_lds(ctx, (const void *)tl_unsort_staged_kernel<ESZ, CH>, (int)lds); if (ast) return ast; }
+    hipLaunchKernelGGL((tl_unsort_staged_kernel<ESZ, CH>), dim3(s->tl_nwg), dim3(TL_THREADS), lds, ctx->stream, (const unsigned *)s->slot, m,
+                       (const unsigned *)s->tl_cnt, s->tl_nb, s->tl_nwg, (const double *)s->res1, d_values, d_leaf);
+  } else {
+    constexpr int CH = TlGeom<3>::CH;
+    const size_t lds = (size_t)CH * ESZ * 8;
+    { int ast = sinterp_func_lds(ctx, (const void *)tl_unsort_staged_kernel<ESZ, CH>, (int)lds); if (ast) return ast; }
+    hipLaunchKernelGGL((tl_unsort_staged_kernel<ESZ, CH>), dim3(s->tl_nwg), dim3(TL_THREADS), lds, ctx->stream, (const unsigned *)s->slot, m,
+                       (const unsigned *)s->tl_cnt, s->tl_nb, s->tl_nwg, (const double *)s->res1, d_values, d_leaf);
+  }
   LAUNCH_CHECK(ctx);
   return ST_SUCCESS;
 }
@@ -765,12 +840,7 @@ int sinterp_unsort_packed(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, siz
   if (m == 0) return ST_SUCCESS;
   size_t blocks = (m + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (s->two_level) {                            /* the sweep stored {value, leaf} pairs at res1[inv[p]] */
-    hipLaunchKernelGGL(tl_unsort_final_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
-                       (const double *)s->res1, d_values, d_leaf);
-    LAUNCH_CHECK(ctx);
-    return ST_SUCCESS;
-  }
+  if (s->two_level) return tl_unsort<2>(ctx, s, m, d_values, d_leaf);   /* the sweep stored {value, leaf} pairs at res1[inv[p]] */
   hipLaunchKernelGGL(unsort_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->cellid,
                      (const unsigned *)s->slot, (const unsigned *)s->offset, m, (const double2 *)s->vs, d_values, d_leaf);
   LAUNCH_CHECK(ctx);
@@ -784,10 +854,7 @@ int sinterp_unsort(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, size_t m, 
   if (blocks > 4096) blocks = 4096;
   if (s->two_level) {                            /* the sweep stored plain values at res1[inv[p]] */
     if (d_leaf) return sinterp_fail(ctx, ST_EINVAL, "unsort: leaf output of a two-level reorder is packed", hipSuccess, __FILE__, __LINE__);
-    hipLaunchKernelGGL(tl_unsort_final_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->slot, m,
-                       (const double *)s->res1, d_values, (int *)NULL);
-    LAUNCH_CHECK(ctx);
-    return ST_SUCCESS;
+    return tl_unsort<1>(ctx, s, m, d_values, (int *)NULL);
   }
   hipLaunchKernelGGL(unsort_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const unsigned *)s->cellid,
                      (const unsigned *)s->slot, (const unsigned *)s->offset, m, (const double *)s->vs, d_values,
