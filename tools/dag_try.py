@@ -1,6 +1,8 @@
-"""Developer tool: the task-DAG Cholesky (chol_dag.hip) against numpy at a few sizes, with timing.
+"""Developer tool: the opt-in task-DAG Cholesky (chol_dag.hip) against numpy at a few sizes, with timing; set
+GSL_SINTERP_CHOL_DAG=0 to time the default driver instead, GSL_SINTERP_DAG_PROF=1 for the chain / worker time stamps.
 usage: python tools/dag_try.py [n ...]"""
 import os, sys, time
+os.environ.setdefault("GSL_SINTERP_CHOL_DAG", "1")
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 import numpy as np, torch
