@@ -268,15 +268,23 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
    one of the per-centre early-out (term < 2^-72 of the kernel maximum), applied to a lower bound
    of the distance, so only terms below that bound are dropped; the summation order is the (fixed)
    Morton order of the centres instead of their input order. */
-#ifndef CT
-#define CT 32      /* 128 until round 2.  A target tests every centre of the tiles its workgroup keeps; smaller tiles hug
-                      the cut-off disc more closely.  Sweep + target sort, ms: C4 (2-D, N = 8192, M = 1e7) 2.41 / 1.97 /
-                      1.73 / 1.58 and C3 (3-D, N = 16384, M = 1e6) 1.96 / 1.75 / 1.70 / 1.74 for CT = 128 / 64 / 32 / 16 */
-#endif
+/* Tile size CT (template parameter: 8, 16 or 32 centres; 128 until round 2).  A target tests every centre of the tiles its
+   workgroup keeps; smaller tiles hug the cut-off disc more closely.  Sweep phase, ms -- round 2: C4 (2-D, N = 8192, M = 1e7)
+   2.41 / 1.97 / 1.73 / 1.58 and C3 (3-D, N = 16384, M = 1e6) 1.96 / 1.75 / 1.70 / 1.74 for CT = 128 / 64 / 32 / 16; round 3 (targets
+   physically reordered by Morton cell, a workgroup = a 2 x 2 block of target cells): C4 1.41 / 1.25 / 1.18 and C3 1.29 / 1.30 / 1.34
+   for CT = 32 / 16 / 8.  So: 8 in two dimensions, 32 otherwise -- and the next larger size while the tile count would exceed
+   CULL_MAX_TILES (the kept-tile bit mask in LDS).  The tile size changes which centres are TESTED, never which terms a target
+   takes nor their order: results are bit-identical for every CT. */
 #define CULL_MAX_TILES 8192
+static inline int cull_tile_size(int dim, size_t n)
+{
+  int ct = dim == 2 ? 8 : 32;
+  while (ct < 32 && (n + ct - 1) / ct > CULL_MAX_TILES) ct *= 2;
+  return ct;
+}
 
-#define CT_THREADS (CT < 64 ? 64 : CT)
-template <int DIM>
+#define CT_THREADS 64
+template <int DIM, int CT>
 __global__ void __launch_bounds__(CT_THREADS)
 centre_pack_kernel(const double *__restrict__ x, size_t n, size_t xtda, const double *__restrict__ w,
                    const int *__restrict__ perm, double *__restrict__ xs, double *__restrict__ tbox)
@@ -313,7 +321,7 @@ centre_pack_kernel(const double *__restrict__ x, size_t n, size_t xtda, const do
 #ifndef CULL_THREADS
 #define CULL_THREADS 128   /* 256 / 128 / 64 threads: C3 sweep 1.34 / 1.26 / 1.27 ms, C4 1.71 ms throughout */
 #endif
-template <int KIND, int DIM, int TPT>
+template <int KIND, int DIM, int TPT, int CT>
 __global__ void __launch_bounds__(CULL_THREADS)
 rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n, const double *__restrict__ tbox, unsigned ntiles,
                            const double *__restrict__ y, size_t m, size_t ytda, double *__restrict__ s, const int *__restrict__ perm,
@@ -433,27 +441,31 @@ static int launch_eval_cull(gsl_sinterp_hip_ctx *ctx, double coef, const double 
     st = sinterp_sort_centres(ctx, d_x, n, xtda, dim, 8, &d_cperm);
     if (st) return st;
   }
-  const unsigned ntiles = (unsigned)((n + CT - 1) / CT);
+  const int ct = cull_tile_size(dim, n);
+  const unsigned ntiles = (unsigned)((n + ct - 1) / ct);
   void *buf = NULL;
   st = sinterp_centbuf(ctx, (n * (size_t)(dim + 1) + (size_t)ntiles * 2 * dim) * sizeof(double), &buf);
   if (st) return st;
   double *xs = (double *)buf, *tbox = xs + n * (size_t)(dim + 1);
   const size_t per_block = (size_t)CULL_THREADS * TPT;
   dim3 grid((unsigned)((m + per_block - 1) / per_block));
+#define CULL_LAUNCH(D, C)                                                                                                              \
+  do {                                                                                                                                 \
+    if (!cached) hipLaunchKernelGGL((centre_pack_kernel<D, C>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w,    \
+                                    (const int *)d_cperm, xs, tbox);                                                                   \
+    hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, D, TPT, C>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, \
+                       n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm, d_omap);                                            \
+  } while (0)
   switch (dim) {
-    case 1:
-      if (!cached) hipLaunchKernelGGL((centre_pack_kernel<1>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 1, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm, d_omap);
-      break;
+    case 1: CULL_LAUNCH(1, 32); break;
     case 2:
-      if (!cached) hipLaunchKernelGGL((centre_pack_kernel<2>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 2, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm, d_omap);
+      if (ct == 8) CULL_LAUNCH(2, 8);
+      else if (ct == 16) CULL_LAUNCH(2, 16);
+      else CULL_LAUNCH(2, 32);
       break;
-    default:
-      if (!cached) hipLaunchKernelGGL((centre_pack_kernel<3>), dim3(ntiles), dim3(CT_THREADS), 0, ctx->stream, d_x, n, xtda, d_w, (const int *)d_cperm, xs, tbox);
-      hipLaunchKernelGGL((rbf_eval_gauss_cull_kernel<KIND, 3, TPT>), grid, dim3(CULL_THREADS), 0, ctx->stream, coef, (const double *)xs, n, (const double *)tbox, ntiles, d_y, m, ytda, d_s, d_perm, d_omap);
-      break;
+    default: CULL_LAUNCH(3, 32); break;
   }
+#undef CULL_LAUNCH
   LAUNCH_CHECK(ctx);
   if (model_id != 0 && !cached) {
     ctx->cent_key.id = model_id; ctx->cent_key.x = d_x; ctx->cent_key.w = d_w; ctx->cent_key.n = n; ctx->cent_key.xtda = xtda;
@@ -589,7 +601,7 @@ static int rbf_eval_dispatch(gsl_sinterp_hip_ctx *ctx, int kind, double coef, co
      runs must not depend on the batch (a target's value is a function of the model and the target alone, so a
      batch split into shards -- or a single-point call -- returns the bits of the one-batch result): it is chosen
      by N only; small batches simply run the culled kernel without the target sort. */
-  if (local && !no_cull && n >= 1024 && (n + CT - 1) / CT <= CULL_MAX_TILES) {
+  if (local && !no_cull && n >= 1024 && (n + 31) / 32 <= CULL_MAX_TILES) {
     /* 3-D: one target per lane also for large batches -- a workgroup's 256 targets span half the box of 512, and
        in three dimensions that removes more tested-and-rejected centres than the second accumulator chain gains
        (C3 sweep 1.70 -> 1.34 ms; 2-D C4: 1.74 vs 1.77 ms, unchanged) */
