@@ -272,10 +272,13 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
    workgroup keeps; smaller tiles hug the cut-off disc more closely.  Sweep phase, ms -- round 2: C4 (2-D, N = 8192, M = 1e7)
    2.41 / 1.97 / 1.73 / 1.58 and C3 (3-D, N = 16384, M = 1e6) 1.96 / 1.75 / 1.70 / 1.74 for CT = 128 / 64 / 32 / 16; round 3 (targets
    physically reordered by Morton cell, a workgroup = a 2 x 2 block of target cells): C4 1.41 / 1.25 / 1.18 and C3 1.29 / 1.30 / 1.34
-   for CT = 32 / 16 / 8.  So: 8 in two dimensions, 32 otherwise -- and the next larger size while the tile count would exceed
+   for CT = 32 / 16 / 8; with the kept tiles batched CULL_STAGE centres per LDS stage (one pair of barriers per 64 centres instead
+   of per tile): C4 1.25 / 1.19 / 1.18 for CT = 16 / 8 / 4, C3 1.255 / 1.253 / 1.29 for CT = 32 / 16 / 8.  So: 8 in two dimensions,
+   32 otherwise -- and the next larger size while the tile count would exceed
    CULL_MAX_TILES (the kept-tile bit mask in LDS).  The tile size changes which centres are TESTED, never which terms a target
    takes nor their order: results are bit-identical for every CT. */
 #define CULL_MAX_TILES 8192
+#define CULL_STAGE 64       /* centres per LDS stage of the culled sweep (a multiple of every tile size) */
 static inline int cull_tile_size(int dim, size_t n)
 {
   int ct = dim == 2 ? 8 : 32;
@@ -328,7 +331,7 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
                 const unsigned *__restrict__ omap)
 {
   __shared__ double s_t0[TBL_N];
-  __shared__ __attribute__((aligned(16))) double s_c[CT * (DIM + 1)];
+  __shared__ __attribute__((aligned(16))) double s_c[CULL_STAGE * (DIM + 1)];
   constexpr int NWV = CULL_THREADS / 64;
   __shared__ double s_blo[DIM][NWV], s_bhi[DIM][NWV];
   __shared__ unsigned long long s_mask[CULL_MAX_TILES / 64];
@@ -383,16 +386,25 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
   }
   __syncthreads();
 
-  for (unsigned mi = 0; mi < nmask; mi++) {
-    unsigned long long mask = s_mask[mi];
-    while (mask) {
+  /* the kept tiles, ascending, CULL_STAGE centres per LDS stage (several small tiles share one pair of barriers) */
+  unsigned mi = 0;
+  unsigned long long mask = nmask ? s_mask[0] : 0ULL;
+  for (;;) {
+    int cnt = 0;
+    __syncthreads();                                       /* the previous stage has been consumed */
+    while (cnt + CT <= CULL_STAGE) {
+      while (!mask && mi + 1 < nmask) mask = s_mask[++mi];
+      if (!mask) break;
       const unsigned t = mi * 64 + (unsigned)__builtin_ctzll(mask);
       mask &= mask - 1;
       const size_t c0 = (size_t)t * CT;
-      const int cnt = (int)((n - c0) < (size_t)CT ? (n - c0) : (size_t)CT);
-      __syncthreads();
-      for (int e = tid; e < cnt * (DIM + 1); e += CULL_THREADS) s_c[e] = xs[c0 * (DIM + 1) + e];
-      __syncthreads();
+      const int tc = (int)((n - c0) < (size_t)CT ? (n - c0) : (size_t)CT);
+      for (int e = tid; e < tc * (DIM + 1); e += CULL_THREADS) s_c[cnt * (DIM + 1) + e] = xs[c0 * (DIM + 1) + e];
+      cnt += tc;
+    }
+    if (cnt == 0) break;
+    __syncthreads();
+    {
 #pragma unroll 2
       for (int e = 0; e < cnt; e++) {
         double xc[DIM];
