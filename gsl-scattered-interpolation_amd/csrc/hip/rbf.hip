@@ -278,7 +278,9 @@ rbf_eval_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
    CULL_MAX_TILES (the kept-tile bit mask in LDS).  The tile size changes which centres are TESTED, never which terms a target
    takes nor their order: results are bit-identical for every CT. */
 #define CULL_MAX_TILES 8192
+#ifndef CULL_STAGE
 #define CULL_STAGE 64       /* centres per LDS stage of the culled sweep (a multiple of every tile size) */
+#endif
 static inline int cull_tile_size(int dim, size_t n)
 {
   int ct = dim == 2 ? 8 : 32;
