@@ -752,26 +752,43 @@ int sinterp_sort_reorder(gsl_sinterp_hip_ctx *ctx, const double *d_y, size_t m, 
   if (m == 0) return ST_SUCCESS;
   if (m_cap < m) m_cap = m;
   if (m_cap > 0x7fffffffULL) return sinterp_fail(ctx, ST_EINVAL, "sort_reorder: more than 2^31 targets", hipSuccess, __FILE__, __LINE__);
-  double cells = (double)m / (double)(per_cell > 0 ? per_cell : 64);
-  int g = (int)ceil(pow(cells < 1 ? 1.0 : cells, 1.0 / dim));
   const int gmax = dim == 1 ? (1 << 20) : (dim == 2 ? 1024 : 100);
-  g = g < 1 ? 1 : (g > gmax ? gmax : g);
-  size_t ncell = 1, ncell_cap = 1;
-  for (int c = 0; c < dim; c++) ncell *= (size_t)g;
-  int gc = 1;
+  /* cells per axis for a batch of mm targets.  The two-level route numbers its cells by Morton code: a power-of-two grid
+     makes the id space dense (runs of ids are compact blocks at every scale) -- C3 sweep 1.27 -> 1.14 ms, C4 1.19 -> 1.15,
+     C5 1.57 -> 1.55 against the same scheme on the 25^3 / 395^2 grids; the nearer power of two in ratio, so a cell holds
+     between per_cell / 2^(dim/2) and per_cell 2^(dim/2) targets.  Monotone in mm (the capacity below relies on it). */
+  auto grid_of = [&](size_t mm) {
+    const double cells = (double)mm / (double)(per_cell > 0 ? per_cell : 64);
+    int gg = (int)ceil(pow(cells < 1 ? 1.0 : cells, 1.0 / dim));
+    gg = gg < 1 ? 1 : (gg > gmax ? gmax : gg);
+    if (dim >= 2 && sort_two_level(mm)) {
+      int p2 = 1;
+      while (p2 * 2 <= gg) p2 *= 2;                    /* p2 <= gg < 2 p2 */
+      gg = ((double)gg / p2 > (double)(2 * p2) / gg) ? 2 * p2 : p2;
+      const int gcap = dim == 2 ? 1024 : 128;
+      if (gg > gcap) gg = gcap;
+    }
+    return gg;
+  };
+  const int g = grid_of(m), gc = grid_of(m_cap);
+  /* the two-level route's id space is (2^bits)^dim, 2^bits >= g (= g^dim for its power-of-two grids) */
+  auto id_space = [&](int gg, bool morton) {
+    int side = gg;
+    if (morton && dim >= 2) { side = 1; while (side < gg) side *= 2; }
+    size_t c = 1;
+    for (int q = 0; q < dim; q++) c *= (size_t)side;
+    return c;
+  };
+  const size_t ncell = id_space(g, sort_two_level(m));
+  size_t ncell_cap = id_space(gc, sort_two_level(m_cap));
   {
-    double cc = (double)m_cap / (double)(per_cell > 0 ? per_cell : 64);
-    gc = (int)ceil(pow(cc < 1 ? 1.0 : cc, 1.0 / dim));
-    gc = gc < 1 ? 1 : (gc > gmax ? gmax : gc);
-    for (int c = 0; c < dim; c++) ncell_cap *= (size_t)gc;
+    /* a smaller batch in a section sized for m_cap may take the one-level route on a (non power-of-two) grid */
+    const double cc = (double)m_cap / (double)(per_cell > 0 ? per_cell : 64);
+    int gr = (int)ceil(pow(cc < 1 ? 1.0 : cc, 1.0 / dim));
+    gr = gr < 1 ? 1 : (gr > gmax ? gmax : gr);
+    const size_t raw = id_space(gr, false);
+    if (ncell_cap < raw) ncell_cap = raw;
     if (ncell_cap < ncell) ncell_cap = ncell;
-  }
-  /* the two-level route numbers the cells by Morton code: the id space is (2^bits)^dim, 2^bits >= g */
-  auto morton_space = [&](int gg) { int bits = 0; while ((1 << bits) < gg) bits++; return (size_t)1 << (bits * dim); };
-  if (sort_two_level(m_cap) && dim >= 2) {
-    const size_t mc = morton_space(gc > g ? gc : g);
-    if (ncell_cap < mc) ncell_cap = mc;
-    if (sort_two_level(m) ) ncell = morton_space(g);
   }
   /* layout: box | ys | vs | ls | cellid | slot | count(+1) [| t_y (later res1) | inv | fin | cnt | ubase | grid : two-level] ; every section
      16-byte aligned */
