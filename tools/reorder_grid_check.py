@@ -1,6 +1,6 @@
-"""Developer check: the two-level reorder when the Morton id space is sparse (3-D, G just above a power of two)."""
+"""Developer check: the 3-D culled sweep over batch sizes whose ideal grid is not a power of two, one-level\n(GSL_SINTERP_SORT_LEVELS=1) against the two-level reorder (which rounds the grid to a power of two)."""
 import os, sys, time
-_R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 import numpy as np, torch
 import __graft_entry__ as g
@@ -22,5 +22,5 @@ for m in (1_000_000, 1_300_000, 2_400_000, 3_000_000, 5_000_000):
             ctx.rbf_eval(0, eps, x.data_ptr(), n, dim, dim, w.data_ptr(), y.data_ptr(), m, dim, s.data_ptr())
             t = ctx.timer_stop()
         out.append(t)
-    G = int(np.ceil((m / float(os.environ.get("RBF_PC", "64"))) ** (1 / 3)))
-    print(f"m={m}: G={G}  one-level {out[0]:.3f} ms  two-level {out[1]:.3f} ms  ({out[1]/m*1e3:.3f} us/target)", flush=True)
+    G = int(np.ceil((m / 64.0) ** (1 / 3)))
+    print(f"m={m}: ideal G={G}  one-level {out[0]:.3f} ms  two-level {out[1]:.3f} ms  ({out[1]/m*1e3:.3f} us/target)", flush=True)
