@@ -1,4 +1,5 @@
-"""Developer check: the 3-D culled sweep over batch sizes whose ideal grid is not a power of two, one-level\n(GSL_SINTERP_SORT_LEVELS=1) against the two-level reorder (which rounds the grid to a power of two)."""
+"""Developer check: the 3-D culled sweep over batch sizes whose ideal grid is not a power of two, one-level
+(GSL_SINTERP_SORT_LEVELS=1) against the two-level reorder (which rounds the grid to a power of two)."""
 import os, sys, time
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
