@@ -368,9 +368,18 @@ unsort_kernel(const unsigned *__restrict__ cellid, const unsigned *__restrict__ 
 #define TL_W 2048
 #define TL_MIN_M (1u << 18)
 #define TL_THREADS 512
+#ifndef TL_CH2
+#define TL_CH2 6144
+#endif
+#ifndef TL_CH3
+#define TL_CH3 4096
+#endif
+#ifndef TL_PU
+#define TL_PU 4096
+#endif
 template <int DIM> struct TlGeom {
-  static constexpr int CH = DIM == 3 ? 4096 : 6144;    /* points per workgroup, coarse passes: CH * 8 DIM + 4 CH bytes of LDS */
-  static constexpr int P = 4096;                       /* points per unit, fine passes: P * (8 DIM + 8) bytes + three windows */
+  static constexpr int CH = DIM == 3 ? TL_CH3 : TL_CH2;   /* points per workgroup, coarse passes: CH * 8 DIM + 4 CH bytes of LDS */
+  static constexpr int P = TL_PU;                         /* points per unit, fine passes: P * (8 DIM + 8) bytes + three windows */
 };
 
 /* cell = Morton (bit-interleaved) code of the per-axis indices i_c = min(g-1, max(0, (int)((y_c - lo_c) f_c))): runs of
