@@ -21,13 +21,13 @@
 
 /* tables live in global memory (built once per context on first use) and are
    copied into LDS by each workgroup */
-#define LOG_BITS 7
+#define LOG_BITS 8
 #define LOG_N (1 << LOG_BITS)
-#define LOG_COPIES 16                 /* LDS replicas of the (1/c, ln c) table: one per lane of a ds_read_b128 pass */
+#define LOG_COPIES 8                  /* LDS replicas of the (1/c, ln c) table: one per PAIR of lanes of a ds_read_b128 pass */
 #define LOG_LDS (LOG_N * LOG_COPIES * 2)   /* doubles: 32 KiB */
 struct RbfTables {
   double exp2_frac[TBL_N];      /* 2^(i/256)                          */
-  double log_pair[LOG_N][2];    /* {1/c_i, ln c_i}, c_i = (1 + (i+0.5)/128)/2 */
+  double log_pair[LOG_N][2];    /* {1/c_i, ln c_i}, c_i = (1 + (i+0.5)/LOG_N)/2 */
 };
 
 __device__ RbfTables g_rbf_tables;
@@ -68,12 +68,15 @@ __device__ __forceinline__ double exp2_tbl(double t, const double *__restrict__ 
 
 /* ln(v), v >= 0 finite: v = 2^e m with m in [1/2, 1) from v_frexp_mant_f64 / v_frexp_exp_i32_f64
    (one instruction each; splitting the high word with integer ops costs five more).  Table index =
-   top 7 mantissa bits; c_i = (1 + (i+0.5)/128)/2 is the midpoint of m's bin, u = m/c_i - 1,
-   |u| <= 2^-8, log1p(u) to u^6 (|u|^7/7 < 2e-18);  ln v = e ln2 + ln c_i + log1p(u).
+   top 8 mantissa bits; c_i = (1 + (i+0.5)/256)/2 is the midpoint of m's bin, u = m/c_i - 1,
+   |u| <= 2^-9, log1p(u) to u^5 (|u|^6/6 < 1e-17);  ln v = e ln2 + ln c_i + log1p(u).
+   (Until round 3: 128 entries, |u| <= 2^-8, one more term -- the larger table trades one FMA of the ~22 VALU
+   instructions per pair for nothing: C2 sweep 2.87 -> 2.80 ms.)
    The lookup is data dependent per lane; a plain LDS table costs ~3x in bank conflicts (measured:
-   31 % of the TPS sweep).  The table is therefore stored as 16 interleaved copies of the 16-byte
-   pair {1/c_i, ln c_i}: row i is 256 bytes = all 64 banks, lane l reads copy l & 15, so each
-   16-lane pass of the ds_read_b128 touches every bank exactly once whatever the indices are.
+   31 % of the TPS sweep).  The table is therefore stored as 8 interleaved copies of the 16-byte
+   pair {1/c_i, ln c_i}: row i is 128 bytes = 32 banks, lane l reads copy l & 7, so a 16-lane pass of the
+   ds_read_b128 meets at most a two-way conflict (lanes l and l + 8) whatever the indices are -- 16 cycles per
+   wave and pair against >= 80 of VALU work (16 copies of 128 entries, conflict free, were the same 32 KiB).
    v = 0 gives a finite value (m = 0 -> u = -1), which the callers multiply by r^2 = 0. */
 template <int COPIES>
 __device__ __forceinline__ double log_tbl(double v, const double *__restrict__ lt_lane)
@@ -83,8 +86,7 @@ __device__ __forceinline__ double log_tbl(double v, const double *__restrict__ l
   const double m = __builtin_amdgcn_frexp_mant(v);
   const int e = __builtin_amdgcn_frexp_exp(v);
   const double u = fma(m, t.x, -1.0);
-  double p = fma(u, -1.0 / 6.0, 0.2);
-  p = fma(p, u, -0.25);
+  double p = fma(u, 0.2, -0.25);
   p = fma(p, u, 1.0 / 3.0);
   p = fma(p, u, -0.5);
   p = fma(p, u, 1.0);
