@@ -978,9 +978,6 @@ static int bary_eval_part(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_r
   return ST_SUCCESS;
 }
 
-#define BARY_CHUNKS 4            /* pieces of a large batch, alternating between the context's two streams */
-#define BARY_CHUNK_MIN (1u << 20)
-
 extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_records,
                                          const void *d_leaftab, const double *h_scale, const double *d_targets,
                                          size_t m, size_t ttda, double *d_values, int *d_leaf,
@@ -999,11 +996,6 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   static const bool no_fast = getenv("GSL_SINTERP_NO_FASTDIV") && getenv("GSL_SINTERP_NO_FASTDIV")[0] == '1';
   static const bool no_affine = getenv("GSL_SINTERP_NO_AFFINE_WALK") && getenv("GSL_SINTERP_NO_AFFINE_WALK")[0] == '1';
   static const bool no_side = getenv("GSL_SINTERP_NO_SIDE_STREAM") && getenv("GSL_SINTERP_NO_SIDE_STREAM")[0] == '1';
-  /* read per call (tests switch them inside one process): opt-in switch (measured slower, below), and the smallest piece
-     worth a stream hop */
-  const bool no_chunks = !(getenv("GSL_SINTERP_BARY_CHUNKS") && getenv("GSL_SINTERP_BARY_CHUNKS")[0] == '1');
-  size_t chunk_min = BARY_CHUNK_MIN;
-  if (getenv("GSL_SINTERP_BARY_CHUNK_MIN") && atol(getenv("GSL_SINTERP_BARY_CHUNK_MIN")) >= 4096) chunk_min = (size_t)atol(getenv("GSL_SINTERP_BARY_CHUNK_MIN"));
   const bool will_sort = m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1');
   /* Large batches: per-batch affine walk records (a pass over the node records: ~n_nodes x 128 bytes) and the
      certified walk; what it could not certify is queued for the exact kernel.  The results do not depend on
@@ -1015,22 +1007,9 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
       if (hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = NULL; }
   }
   const bool side = use_walk && !no_side && ctx->side_stream != NULL;
-  /* Pipeline (round 3): NEGATIVE RESULT, kept as an opt-in knob (GSL_SINTERP_BARY_CHUNKS=1).  The cell sort of the
-     targets is bound by returning L2 atomics and scattered 16-byte stores, the certified walk by dependent record
-     gathers through L1 / the texture addressers: different units, run one after the other (0.73 ms of sorting in
-     front of 1.0 ms of locating at C5).  Idea: cut a large batch into BARY_CHUNKS pieces that alternate between the
-     context's stream and its side stream, so that chunk i+1 is binned and gathered while chunk i walks (each piece
-     with its own section of the sort and walk buffers; a value depends on (records, target) only, so the split
-     changes no bit -- test_chunked_two_stream_pipeline_changes_no_bit).  Measured at C5 (rocprofv3 kernel trace,
-     profiles/r03_C5_chunked_two_stream_trace.txt vs r03_C5_single_batch_trace.txt): 2.17 ms against 2.01 ms.  The
-     two queues do run concurrently (>= 2 kernels in flight for 1.98 of 2.2 ms), but (i) the latency-bound kernels
-     do not shrink with the batch: bary_walk 353-484 us per 2.5 M-target chunk against 733 us for all 10 M (two
-     256-target slices per persistent wave instead of eight: the tail of the longest walks dominates), bary_start
-     110-157 us against 153 us, the exact kernel's 0.01 % queue 61-133 us per chunk against 105 us once; (ii) the
-     pieces that overlap are mostly of the same kind (hist beside hist, walk beside walk: each then takes its
-     share of the same unit).  Chunking multiplies the fixed costs by four and overlaps little of what remains. */
-  const int n_chunks = (side && !no_chunks && m >= (size_t)BARY_CHUNKS * chunk_min) ? BARY_CHUNKS : 1;
-  const size_t m_cap = n_chunks > 1 ? (((m + n_chunks - 1) / n_chunks + WALK_SLICE - 1) / WALK_SLICE) * WALK_SLICE : m;
+  /* (cutting a large batch into chunks on two streams was measured slower in round 3 -- DESIGN.md 6 -- and removed) */
+  const int n_chunks = 1;
+  const size_t m_cap = m;
   WalkRec *wrec = NULL;
   char *wsec[2] = {NULL, NULL};
   if (use_walk) {
@@ -1057,26 +1036,12 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
     if (side) HIP_OK(ctx, hipEventRecord(ctx->side_ev[1], ctx->side_stream));
   }
   int st = ST_SUCCESS;
-  if (n_chunks == 1) {
+  {
     /* the walk records are built on the side stream while the targets are sorted on the main one; the sort comes
        first inside bary_eval_part, so the join is placed in front of it only when there is no side stream */
     if (side) HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));
     st = bary_eval_part(ctx, n_nodes, d_records, d_leaftab, h_scale, d_targets, m, ttda, d_values, d_leaf, d_count, wrec, wsec[0], m_cap,
                         -1, side);
-  } else {
-    hipStream_t main_stream = ctx->stream;
-    HIP_OK(ctx, hipStreamWaitEvent(main_stream, ctx->side_ev[1], 0));     /* walk records (the side stream is ordered behind them) */
-    const size_t per = (m + n_chunks - 1) / n_chunks;
-    for (int c = 0; c < n_chunks && st == ST_SUCCESS; c++) {
-      const size_t first = (size_t)c * per, cnt = first >= m ? 0 : (m - first < per ? m - first : per);
-      if (!cnt) break;
-      ctx->stream = (c & 1) ? ctx->side_stream : main_stream;
-      st = bary_eval_part(ctx, n_nodes, d_records, d_leaftab, h_scale, d_targets + first * ttda, cnt, ttda, d_values + first,
-                          d_leaf ? d_leaf + first : (int *)NULL, d_count, wrec, wsec[c & 1], m_cap, c & 1, false);
-    }
-    ctx->stream = main_stream;
-    HIP_OK(ctx, hipEventRecord(ctx->side_ev[3], ctx->side_stream));       /* join the odd chunks */
-    HIP_OK(ctx, hipStreamWaitEvent(main_stream, ctx->side_ev[3], 0));
   }
   if (st) return st;
   if (h_n_outside) {

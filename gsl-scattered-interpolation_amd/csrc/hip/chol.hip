@@ -303,33 +303,6 @@ tricpy_lower_to_upper_kernel(double *__restrict__ A, size_t lda, size_t n)
   }
 }
 
-/* Look-ahead.  The update of the right half after a panel is split by columns: the part the
-   next sub-panel needs first (G_a) stays on the main stream, the rest (G_b) runs on an auxiliary
-   stream and is joined just before the recursion touches those columns.  The latency-bound panel
-   kernels of the next sub-panel then overlap with a large MFMA GEMM instead of idling the chip.
-   Under stream capture the fork/join events become edges of the hipGraph. */
-struct Pend { hipEvent_t ev; size_t col; bool active; };
-
-static int la_event(gsl_sinterp_hip_ctx *ctx, hipEvent_t *out)
-{
-  if (ctx->la_events_used >= 4096) return sinterp_fail(ctx, ST_EFAILED, "look-ahead event pool exhausted", hipSuccess, __FILE__, __LINE__);
-  if (ctx->la_events_used >= ctx->la_events_made) {
-    HIP_OK(ctx, hipEventCreateWithFlags(&ctx->la_event[ctx->la_events_made], hipEventDisableTiming));
-    ctx->la_events_made++;
-  }
-  *out = ctx->la_event[ctx->la_events_used++];
-  return ST_SUCCESS;
-}
-
-static int join_pend(gsl_sinterp_hip_ctx *ctx, Pend *p)
-{
-  if (p && p->active) {
-    HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, p->ev, 0));
-    p->active = false;
-  }
-  return ST_SUCCESS;
-}
-
 /* width of the left part of a panel of width w > CB: half, rounded up to a 128-column boundary while
    the panel is wider than 128 (so the recursion ends in exact 128-wide panels), to 32 below */
 static size_t chol_split(size_t w)
@@ -341,12 +314,11 @@ static size_t chol_split(size_t w)
 }
 
 static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, size_t j0, size_t w, int *d_info,
-                      double *d_diag, int depth, Pend *pend)
+                      double *d_diag)
 {
   int st;
   static const bool no_p128 = getenv("GSL_SINTERP_NO_PANEL128") && getenv("GSL_SINTERP_NO_PANEL128")[0] == '1';
   if (w == PB && !no_p128 && (lda & 1) == 0 && ((((uintptr_t)(A + j0 * lda + j0)) & 15) == 0)) {
-    if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
     double *d_linv = d_diag + ((n + CB - 1) / CB) * (CB * CB);   /* 4 inverted 32x32 blocks */
     const size_t lds_diag = (size_t)(14 * PBLK) * sizeof(double), lds_trsm = (size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double);
     { int ast = sinterp_func_lds(ctx, (const void *)chol_diag128_kernel, (int)lds_diag); if (ast) return ast; }
@@ -360,7 +332,6 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
     return ST_SUCCESS;
   }
   if (w <= CB) {
-    if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
     const size_t below = n - j0 - w;
     const unsigned grid = (unsigned)((below + 255) / 256) + (below == 0 ? 1u : 0u);
     hipLaunchKernelGGL(chol_base_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream, A, lda, n, j0, (int)w, d_info, d_diag);
@@ -368,212 +339,14 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
     return ST_SUCCESS;
   }
   const size_t w1 = chol_split(w);
-  st = chol_panel(ctx, A, lda, n, j0, w1, d_info, d_diag, depth + 1, pend);
+  st = chol_panel(ctx, A, lda, n, j0, w1, d_info, d_diag);
   if (st) return st;
-  if (pend && pend->active && pend->col < j0 + w) { st = join_pend(ctx, pend); if (st) return st; }
   const size_t r0 = j0 + w1, w2 = w - w1;
-  const bool fork = ctx->use_lookahead && depth < 15 && w1 >= 256 && w2 > CB;
-  if (!fork) {
-    st = sinterp_gemm_minus(ctx, n - r0, w2, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
-    if (st) return st;
-    return chol_panel(ctx, A, lda, n, r0, w2, d_info, d_diag, depth + 1, NULL);
-  }
-  /* same split the recursion on the right half will make */
-  const size_t w2a = chol_split(w2);
-  const size_t w2b = w2 - w2a, rb = r0 + w2a;
-  if (!ctx->la_stream[depth]) HIP_OK(ctx, hipStreamCreateWithFlags(&ctx->la_stream[depth], hipStreamNonBlocking));
-  hipStream_t aux = ctx->la_stream[depth], mainst = ctx->stream;
-  hipEvent_t e_left, e_gb;
-  st = la_event(ctx, &e_left); if (st) return st;
-  st = la_event(ctx, &e_gb); if (st) return st;
-  HIP_OK(ctx, hipEventRecord(e_left, mainst));
-  HIP_OK(ctx, hipStreamWaitEvent(aux, e_left, 0));
-  ctx->stream = aux;                                     /* G_b: columns [rb, r0+w2), rows >= rb */
-  st = sinterp_gemm_minus(ctx, n - rb, w2b, w1, A + rb * lda + j0, lda, A + rb * lda + j0, lda, 0, A + rb * lda + rb, lda, 1);
-  ctx->stream = mainst;
+  st = sinterp_gemm_minus(ctx, n - r0, w2, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
   if (st) return st;
-  HIP_OK(ctx, hipEventRecord(e_gb, aux));
-  /* G_a: columns [r0, rb), rows >= r0 */
-  st = sinterp_gemm_minus(ctx, n - r0, w2a, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
-  if (st) return st;
-  Pend mine = {e_gb, rb, true};
-  st = chol_panel(ctx, A, lda, n, r0, w2, d_info, d_diag, depth + 1, &mine);
-  if (st) return st;
-  return join_pend(ctx, &mine);
+  return chol_panel(ctx, A, lda, n, r0, w2, d_info, d_diag);
 }
 
-
-/* ------------------------------------------------------------------------ */
-/* Panel look-ahead (round 3).  In the plain recursion above every 128-wide panel costs a dependent chain
-       diag128 (27 us, ONE workgroup) -> trsm128 of all rows below -> the update that brings the next panel's
-       columns up to date (K = 128: 19 us, K = 256: 45 us, K = 512: 107 us, ... for the whole trailing block)
-   during which the chip is mostly idle (N = 16384: 9.9 ms of 32; N = 8192: 24 %, N = 4096: 32 % of the init).
-   The next diagonal block only needs ITS 128 x 128 tile updated, and the next row solve only the tile below it.
-   So the work is cut along that line and issued on two streams (edges of the captured graph):
-       main (the chain):  A-update = tile (p, p) -= L(p, K) L(p, K)^T  ->  diag128(p)  ->  trsm128 of the next 128 rows
-       side (the bulk):   trsm128 of the remaining rows  ->  B-update = the rows below of column block p+1
-                          -> C-update = the rest of the trailing block            (stream-K on all but LA_RESERVE CUs)
-   for every update with K <= LA_KMAX; larger updates (the 15 top nodes of the recursion at N = 16384) stay one launch on
-   the side stream with the chain waiting for it, as before.  Dependencies are hipEvents per panel:
-       E_diag[p]  main  L(p,p) and its inverted 32 x 32 blocks written          -> side trsm of panel p
-       E_crit[p]  main  tile (p+1, p) solved                                    -> side updates that read row block p+1
-       E_rest[p]  side  tiles (>= p+2, p) solved                                -> main A-updates that read row block >= p+2
-       E_B[p]     side  last update of tile (p+1, p)                            -> main trsm of that tile
-       E_dw[p]    side  last update of the diagonal tile (p, p) by the bulk     -> main A-update / diag128 of block p
-   The arithmetic per entry is the recursion's (same K ranges in the same order, the same kernels), only the tiling of
-   one update into launches differs: results agree with the plain driver to rounding of the stream-K split (both are
-   held to the oracle at 1e-12; tests/test_gpu_switches.py runs the linalg / RBF parity tests with it).
-   NEGATIVE RESULT, opt-in (GSL_SINTERP_PANEL_LA=1).  Measured on MI355X (bench.py, init phase): N = 4096 3.12 vs 2.76 ms,
-   N = 8192 7.70 vs 7.23 ms, N = 16384 32.85 vs 32.33 ms -- slower everywhere.  The kernel trace
-   (profiles/r03_chol_panel_lookahead_trace_N4096.txt) shows why: the two queues do overlap as planned (the bulk trsm
-   and B-update run beside the chain's trsm / A-update / diag128), but every dependency that crosses the queues costs
-   5-9 us of signal latency inside the replayed graph against ~1.5 us between dependent kernels of one stream, and
-   the chain crosses twice per panel; diag128-to-diag128 is 72 us with the look-ahead against 62 us (K = 128 nodes)
-   and 84 us (K = 256 nodes) without.  Overlapping the chain needs in-kernel hand-offs (a persistent panel kernel),
-   not streams. */
-#define LA_KMAX 512
-#define LA_RESERVE 8
-#define LA_MAX_PANELS 448
-
-struct LaCtx {
-  gsl_sinterp_hip_ctx *ctx;
-  double *A; size_t lda, n;
-  int *d_info; double *d_diag, *d_linv;
-  hipStream_t main, side;
-  hipEvent_t e_diag[LA_MAX_PANELS], e_crit[LA_MAX_PANELS], e_rest[LA_MAX_PANELS], e_b[LA_MAX_PANELS], e_dw[LA_MAX_PANELS];
-  hipEvent_t last_side;
-};
-
-static int la_wait(LaCtx &L, hipStream_t s, hipEvent_t ev)
-{
-  if (ev) HIP_OK(L.ctx, hipStreamWaitEvent(s, ev, 0));
-  return ST_SUCCESS;
-}
-
-static int la_record(LaCtx &L, hipStream_t s, hipEvent_t *out)
-{
-  hipEvent_t ev;
-  int st = la_event(L.ctx, &ev);
-  if (st) return st;
-  HIP_OK(L.ctx, hipEventRecord(ev, s));
-  *out = ev;
-  if (s == L.side) L.last_side = ev;
-  return ST_SUCCESS;
-}
-
-static int la_leaf(LaCtx &L, size_t j0)
-{
-  gsl_sinterp_hip_ctx *ctx = L.ctx;
-  const size_t p = j0 / PB, n = L.n;
-  int st;
-  const size_t lds_diag = (size_t)(14 * PBLK) * sizeof(double), lds_trsm = (size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double);
-  double *linv = L.d_linv + p * (4 * 1024);
-  if ((st = la_wait(L, L.main, L.e_dw[p]))) return st;                 /* the bulk's last word on tile (p, p) */
-  hipLaunchKernelGGL(chol_diag128_kernel, dim3(1), dim3(256), lds_diag, L.main, L.A, L.lda, j0, L.d_info, L.d_diag, linv);
-  if ((st = la_record(L, L.main, &L.e_diag[p]))) return st;
-  const size_t below = n - j0 - PB;
-  if (below == 0) { LAUNCH_CHECK(ctx); return ST_SUCCESS; }
-  const size_t crit = below < PB ? below : PB;
-  if ((st = la_wait(L, L.main, L.e_b[p]))) return st;
-  hipLaunchKernelGGL(chol_trsm128_kernel, dim3((unsigned)((crit + 63) / 64)), dim3(256), lds_trsm, L.main, L.A, L.lda, j0 + PB + crit, j0,
-                     (const double *)linv, j0 + PB);
-  if ((st = la_record(L, L.main, &L.e_crit[p]))) return st;
-  if (below > crit) {
-    if ((st = la_wait(L, L.side, L.e_diag[p]))) return st;
-    hipLaunchKernelGGL(chol_trsm128_kernel, dim3((unsigned)((below - crit + 63) / 64)), dim3(256), lds_trsm, L.side, L.A, L.lda, n, j0,
-                       (const double *)linv, j0 + PB + crit);
-    if ((st = la_record(L, L.side, &L.e_rest[p]))) return st;
-  }
-  LAUNCH_CHECK(ctx);
-  return ST_SUCCESS;
-}
-
-/* C[r0.., r0 .. r0+w2) -= L[r0.., j0 .. j0+w1) L[r0 .. r0+w2, j0 .. j0+w1)^T, lower trapezoid */
-static int la_update(LaCtx &L, size_t j0, size_t w1, size_t r0, size_t w2)
-{
-  gsl_sinterp_hip_ctx *ctx = L.ctx;
-  double *A = L.A;
-  const size_t lda = L.lda, n = L.n, pr = r0 / PB, q0 = j0 / PB;
-  int st;
-  hipEvent_t ev;
-  if (w1 > LA_KMAX) {
-    /* a large update: one launch on the side stream, the chain waits for it (E_dw / E_b of the blocks it touches) */
-    if (pr >= 1 && (st = la_wait(L, L.side, L.e_crit[pr - 1]))) return st;
-    ctx->stream = L.side; ctx->sk_cap = 0; ctx->sk_alt = 0;
-    st = sinterp_gemm_minus(ctx, n - r0, w2, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
-    ctx->stream = L.main;
-    if (st) return st;
-    if ((st = la_record(L, L.side, &ev))) return st;
-    for (size_t q = pr; q < pr + w2 / PB && q < LA_MAX_PANELS; q++) { L.e_dw[q] = ev; L.e_b[q] = ev; }
-    return ST_SUCCESS;
-  }
-  /* main: the next diagonal block.  Reads L(pr, q0 .. pr-1): the last tile from the chain itself, the older ones from the bulk */
-  if ((st = la_wait(L, L.main, L.e_dw[pr]))) return st;
-  if (pr >= 2 && pr - 2 >= q0 && (st = la_wait(L, L.main, L.e_rest[pr - 2]))) return st;
-  ctx->stream = L.main; ctx->sk_cap = 0; ctx->sk_alt = 1;
-  st = sinterp_gemm_minus(ctx, PB, PB, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
-  ctx->sk_alt = 0;
-  if (st) return st;
-  /* side: everything below the block.  Reads row block pr (tile (pr, pr-1) comes from the chain) */
-  const size_t mb = n - r0 - PB;
-  if (mb > 0) {
-    if (pr >= 1 && (st = la_wait(L, L.side, L.e_crit[pr - 1]))) return st;
-    ctx->stream = L.side; ctx->sk_cap = ctx->sk_wgs > 2 * LA_RESERVE ? ctx->sk_wgs - LA_RESERVE : 0;
-    st = sinterp_gemm_minus(ctx, mb, PB, w1, A + (r0 + PB) * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + (r0 + PB) * lda + r0, lda, 0);
-    if (!st) st = la_record(L, L.side, &ev);
-    if (!st) L.e_b[pr] = ev;
-    if (!st && w2 > PB) {
-      st = sinterp_gemm_minus(ctx, mb, w2 - PB, w1, A + (r0 + PB) * lda + j0, lda, A + (r0 + PB) * lda + j0, lda, 0,
-                              A + (r0 + PB) * lda + r0 + PB, lda, 1);
-      if (!st) st = la_record(L, L.side, &ev);
-      if (!st) for (size_t q = pr + 1; q < pr + w2 / PB && q < LA_MAX_PANELS; q++) { L.e_dw[q] = ev; L.e_b[q] = ev; }
-    }
-    ctx->stream = L.main; ctx->sk_cap = 0;
-    if (st) return st;
-  }
-  return ST_SUCCESS;
-}
-
-static int la_panel(LaCtx &L, size_t j0, size_t w)
-{
-  if (w == PB) return la_leaf(L, j0);
-  const size_t w1 = chol_split(w);
-  int st = la_panel(L, j0, w1);
-  if (st) return st;
-  st = la_update(L, j0, w1, j0 + w1, w - w1);
-  if (st) return st;
-  return la_panel(L, j0 + w1, w - w1);
-}
-
-/* n = 128 T: the whole factorisation with panel look-ahead; ctx->stream is the (capturing) main stream */
-static int chol_lookahead(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, int *d_info, double *d_diag, double *d_linv)
-{
-  LaCtx *Lp = (LaCtx *)calloc(1, sizeof(LaCtx));          /* ~18 KB of event handles: not on the stack of a recursion */
-  if (!Lp) return sinterp_fail(ctx, ST_ENOMEM, "look-ahead state", hipSuccess, __FILE__, __LINE__);
-  struct Guard { LaCtx *p; ~Guard() { free(p); } } guard{Lp};
-  LaCtx &L = *Lp;
-  L.ctx = ctx; L.A = A; L.lda = lda; L.n = n; L.d_info = d_info; L.d_diag = d_diag; L.d_linv = d_linv;
-  if (!ctx->la_stream[0]) HIP_OK(ctx, hipStreamCreateWithFlags(&ctx->la_stream[0], hipStreamNonBlocking));
-  L.main = ctx->stream; L.side = ctx->la_stream[0];
-  { int ast = sinterp_func_lds(ctx, (const void *)chol_diag128_kernel, (int)((size_t)(14 * PBLK) * sizeof(double))); if (ast) return ast; }
-  { int ast = sinterp_func_lds(ctx, (const void *)chol_trsm128_kernel, (int)((size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double))); if (ast) return ast; }
-  /* fork: the side stream starts behind whatever the main stream has done so far (and joins the capture) */
-  hipEvent_t fork;
-  int st = la_event(ctx, &fork);
-  if (st) return st;
-  HIP_OK(ctx, hipEventRecord(fork, L.main));
-  HIP_OK(ctx, hipStreamWaitEvent(L.side, fork, 0));
-  st = la_panel(L, 0, n);
-  ctx->stream = L.main; ctx->sk_cap = 0; ctx->sk_alt = 0;
-  /* join */
-  hipEvent_t join;
-  int st2 = la_event(ctx, &join);
-  if (!st2) {
-    if (hipEventRecord(join, L.side) != hipSuccess || hipStreamWaitEvent(L.main, join, 0) != hipSuccess)
-      st2 = sinterp_fail(ctx, ST_EFAILED, "look-ahead join", hipSuccess, __FILE__, __LINE__);
-  }
-  return st ? st : st2;
-}
 
 __global__ void chol_zero_info_kernel(int *info) { *info = 0; }
 
@@ -598,22 +371,6 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
   if (st) return st;
   st = sinterp_streamk_prepare(ctx);
   if (st) return st;
-  if (sinterp_cholesky_dag_applicable(n, d_a, lda)) {
-    /* one persistent task-DAG launch (chol_dag.hip) */
-    const unsigned nt = (unsigned)((n + 31) / 32);
-    if (!symmetric_input) hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
-    int done = 0, dinfo = 0;
-    st = sinterp_cholesky_dag(ctx, n, d_a, lda, &dinfo, &done);
-    if (st) return st;
-    if (done) {
-      if (h_info) *h_info = dinfo;
-      if (dinfo) {
-        snprintf(ctx->err, sizeof ctx->err, "cholesky_decomp1: matrix is not positive definite (pivot %d of %zu <= 0)", dinfo, n);
-        return ST_EDOM;
-      }
-      return ST_SUCCESS;
-    }
-  }
   int replayed = 0;
   const void *gkey = symmetric_input ? (const void *)(uintptr_t)1 : NULL;
   st = sinterp_graph_try_launch(ctx, 0, n, lda, d_a, gkey, &replayed);
@@ -628,14 +385,7 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
     hipError_t me = hipSuccess;
     const unsigned nt = (unsigned)((n + 31) / 32);
     if (!symmetric_input) hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
-    ctx->la_events_used = 0;
-    /* opt-in: measured slower than the plain recursion (see the comment above chol_lookahead) */
-    static const bool no_la = !(getenv("GSL_SINTERP_PANEL_LA") && getenv("GSL_SINTERP_PANEL_LA")[0] == '1');
-    static const bool no_p128 = getenv("GSL_SINTERP_NO_PANEL128") && getenv("GSL_SINTERP_NO_PANEL128")[0] == '1';
-    const bool la = !no_la && !no_p128 && !ctx->use_lookahead && ctx->sk_wgs > 2 * LA_RESERVE && n % PB == 0 && n >= 2 * PB && n_pan <= LA_MAX_PANELS &&
-                    (lda & 1) == 0 && ((((uintptr_t)d_a) & 15) == 0);
-    if (la) st = chol_lookahead(ctx, d_a, lda, n, d_info, (double *)d_diag, (double *)d_diag + nblk * (CB * CB));
-    else st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag, 0, NULL);
+    st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag);
     hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
                        (const double *)d_diag);
     int st2 = sinterp_capture_end(ctx, saved, 0, n, lda, d_a, gkey);
@@ -1108,208 +858,6 @@ trsv_dataflow_kernel(const double *__restrict__ T, size_t ldt, size_t n, const d
   }
 }
 
-/* ---- two consecutive blocks of the sweep per workgroup -----------------------------------------
-   NEGATIVE RESULT, opt-in (GSL_SINTERP_TRSV_PAIRS=1): halving the grid-wide hand-offs does not shorten the sweep --
-   the second block's solve inside the workgroup (reduce, barrier, 64 x 64 matvec, barrier: ~1 us) plus the second
-   poll per unit cost what the hand-off cost (C3 init 33.1 -> 33.6 ms).  The chain is bound by the per-block
-   reduce + matvec + two barriers as much as by the hop.
-   The dependent chain of the kernel above is one grid-wide hand-off (sc1 store -> sc1 poll, ~2.3 us) per
-   64-row block: 256 steps per sweep at N = 16384, 0.6 ms for 1.07 GB of matrix.  Here a workgroup owns the
-   blocks 2u and 2u+1 of the sweep order: both block rows stream the tiles of the earlier blocks together (two
-   tiles per received x_J), block 2u is solved, its x goes to block 2u+1 through LDS (no hand-off: the tile
-   T(2u+1, 2u) and W_{2u+1} were fetched at the start), block 2u+1 is solved, both are published.  Half the
-   grid-wide steps; a workgroup still only waits on blocks of workgroups dispatched before it. */
-__global__ void __launch_bounds__(256)
-trsv_dataflow_pair_kernel(const double *__restrict__ T, size_t ldt, size_t n, const double *__restrict__ b, double *xout, size_t ldb,
-                          int nrhs, int mode, const double *__restrict__ Dinv, unsigned *tf, unsigned long long *xq, unsigned nblk)
-{
-  constexpr int NQ = (TRSV_MAXR * TS + 255) / 256;
-  const unsigned want = __hip_atomic_load(tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-  const size_t npad = (size_t)nblk * TS;
-  __shared__ double sx[2][TRSV_MAXR][TS];
-  __shared__ double sxl[TRSV_MAXR][TS];                  /* x of this workgroup's first block, for its second */
-  __shared__ double sW[TS][TS + 1];
-  __shared__ double srhs[TRSV_MAXR][TS];
-  __shared__ double s_part[TRSV_MAXR][4][TS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rsub = lane >> 3, c8 = (lane & 7) * 8;
-  const unsigned nunits = (nblk + 1) / 2;
-
-  /* this thread's slice of tile T(I, J) (the layouts of trsv_dataflow_kernel) */
-  auto load_tile = [&](double (&tt)[16], unsigned I, unsigned J) {
-    const size_t i0 = (size_t)I * TS, j0 = (size_t)J * TS;
-    const int nbI = (int)((n - i0) < TS ? (n - i0) : TS);
-    if (mode == 1) {
-#pragma unroll
-      for (int jj = 0; jj < 16; jj++) {
-        const size_t jr = j0 + wave * 16 + jj;
-        tt[jj] = (jr < n && lane < nbI) ? T[jr * ldt + i0 + lane] : 0.0;
-      }
-    } else {
-#pragma unroll
-      for (int pass = 0; pass < 2; pass++) {
-        const size_t i = i0 + pass * 32 + wave * 8 + rsub;
-        const double *row = T + i * ldt + j0 + c8;
-        if (i < n && j0 + TS <= n && ((((uintptr_t)row) & 15) == 0)) {
-#pragma unroll
-          for (int k = 0; k < 8; k += 2) { const double2 v = *reinterpret_cast<const double2 *>(row + k); tt[pass * 8 + k] = v.x; tt[pass * 8 + k + 1] = v.y; }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 8; k++) tt[pass * 8 + k] = (i < n && j0 + c8 + k < n) ? row[k] : 0.0;
-        }
-      }
-    }
-  };
-  /* acc += tile * x, x = xs[r][0..63] in LDS */
-  auto accumulate = [&](double (&acc)[TRSV_MAXR][2], const double (&tt)[16], const double (*xs)[TS]) {
-    if (mode == 1) {
-#pragma unroll
-      for (int r = 0; r < TRSV_MAXR; r++)
-        if (r < nrhs) {
-#pragma unroll
-          for (int jj = 0; jj < 16; jj++) acc[r][0] = fma(tt[jj], xs[r][wave * 16 + jj], acc[r][0]);
-        }
-    } else {
-#pragma unroll
-      for (int r = 0; r < TRSV_MAXR; r++)
-        if (r < nrhs) {
-#pragma unroll
-          for (int pass = 0; pass < 2; pass++)
-#pragma unroll
-            for (int k = 0; k < 8; k++) acc[r][pass] = fma(tt[pass * 8 + k], xs[r][c8 + k], acc[r][pass]);
-        }
-    }
-  };
-  /* x_I = W (b_I - sum) for the block whose W is in sW; returns with srhs / s_part free again.  Publishes. */
-  auto solve_block = [&](unsigned I, const double (&acc)[TRSV_MAXR][2], const double (&bpre)[NQ], bool keep_local) {
-    const size_t i0 = (size_t)I * TS;
-    const int nbI = (int)((n - i0) < TS ? (n - i0) : TS);
-    if (mode == 1) {
-#pragma unroll
-      for (int r = 0; r < TRSV_MAXR; r++) if (r < nrhs) s_part[r][wave][lane] = acc[r][0];
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        const int e = q * 256 + tid, r = e / TS, c = e % TS;
-        if (e < nrhs * TS) {
-          const double sum = (s_part[r][0][c] + s_part[r][1][c]) + (s_part[r][2][c] + s_part[r][3][c]);
-          srhs[r][c] = (c < nbI) ? bpre[q] - sum : 0.0;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < TRSV_MAXR; r++)
-        if (r < nrhs) {
-#pragma unroll
-          for (int pass = 0; pass < 2; pass++) {
-            double a = acc[r][pass];
-            a += __shfl_xor(a, 1);
-            a += __shfl_xor(a, 2);
-            a += __shfl_xor(a, 4);
-            const int row = pass * 32 + wave * 8 + rsub;
-            if ((lane & 7) == 0) srhs[r][row] = -a;
-          }
-        }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        const int e = q * 256 + tid, r = e / TS, c = e % TS;
-        if (e < nrhs * TS) srhs[r][c] = (c < nbI) ? bpre[q] + srhs[r][c] : 0.0;
-      }
-    }
-    __syncthreads();
-    for (int r = wave; r < nrhs; r += 4) {
-      double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-      if (mode == 0) {
-#pragma unroll
-        for (int c = 0; c < TS; c += 4) {
-          p0 = fma(sW[lane][c], srhs[r][c], p0); p1 = fma(sW[lane][c + 1], srhs[r][c + 1], p1);
-          p2 = fma(sW[lane][c + 2], srhs[r][c + 2], p2); p3 = fma(sW[lane][c + 3], srhs[r][c + 3], p3);
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < TS; c += 4) {
-          p0 = fma(sW[c][lane], srhs[r][c], p0); p1 = fma(sW[c + 1][lane], srhs[r][c + 1], p1);
-          p2 = fma(sW[c + 2][lane], srhs[r][c + 2], p2); p3 = fma(sW[c + 3][lane], srhs[r][c + 3], p3);
-        }
-      }
-      const double xv = (lane < nbI) ? (p0 + p1) + (p2 + p3) : 0.0;
-      if (keep_local) sxl[r][lane] = xv;
-      if (lane < nbI) {
-        unsigned long long *q = xq + 2 * ((size_t)r * npad + i0 + lane);
-        const unsigned long long tag = (unsigned long long)want << 32;
-        __hip_atomic_store(q, tag | (unsigned)__double2loint(xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(q + 1, tag | (unsigned)__double2hiint(xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        xout[r * ldb + i0 + lane] = xv;
-      }
-    }
-    __syncthreads();                                     /* sxl complete; srhs / s_part / sW free */
-  };
-
-  for (unsigned u = blockIdx.x; u < nunits; u += gridDim.x) {
-    const unsigned t0 = 2 * u, t1 = t0 + 1;
-    const bool two = t1 < nblk;
-    const unsigned I0 = (mode == 0) ? t0 : nblk - 1 - t0;
-    const unsigned I1 = two ? ((mode == 0) ? t1 : nblk - 1 - t1) : I0;
-    __syncthreads();                                     /* previous unit of this workgroup fully done with LDS */
-    for (int e = tid; e < TS * TS; e += 256) sW[e / TS][e % TS] = Dinv[(size_t)I0 * (TS * TS) + e];
-    /* everything the second block needs that does not depend on any x: its W, its right-hand side, the tile
-       that couples it to the first block -- in registers, off the dependent path */
-    double wpre[16], tloc[16], bpre0[NQ], bpre1[NQ];
-#pragma unroll
-    for (int q = 0; q < 16; q++) wpre[q] = two ? Dinv[(size_t)I1 * (TS * TS) + q * 256 + tid] : 0.0;
-    if (two) load_tile(tloc, I1, I0);
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      const int e = q * 256 + tid, r = e / TS, c = e % TS;
-      const size_t i0 = (size_t)I0 * TS, i1 = (size_t)I1 * TS;
-      bpre0[q] = (e < nrhs * TS && i0 + c < n) ? b[r * ldb + i0 + c] : 0.0;
-      bpre1[q] = (two && e < nrhs * TS && i1 + c < n) ? b[r * ldb + i1 + c] : 0.0;
-    }
-    double acc0[TRSV_MAXR][2], acc1[TRSV_MAXR][2];
-#pragma unroll
-    for (int r = 0; r < TRSV_MAXR; r++) acc0[r][0] = acc0[r][1] = acc1[r][0] = acc1[r][1] = 0.0;
-    for (unsigned sstep = 0; sstep < t0; sstep++) {
-      const unsigned J = (mode == 0) ? sstep : nblk - 1 - sstep;
-      const size_t j0 = (size_t)J * TS;
-      double tt0[16], tt1[16];
-      load_tile(tt0, I0, J);                             /* independent of x_J: in flight while we wait for it */
-      if (two) load_tile(tt1, I1, J);
-      const int buf = sstep & 1;
-      for (int e = tid; e < nrhs * TS; e += 256) {
-        const int r = e / TS, c = e % TS;
-        double v = 0.0;
-        if (j0 + c < n) {
-          const unsigned long long *q = xq + 2 * ((size_t)r * npad + j0 + c);
-          unsigned long long w0, w1;
-          for (;;) {
-            w0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(w0 >> 32) == want && (unsigned)(w1 >> 32) == want) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
-          v = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
-        }
-        sx[buf][r][c] = v;
-      }
-      __syncthreads();
-      accumulate(acc0, tt0, sx[buf]);
-      if (two) accumulate(acc1, tt1, sx[buf]);
-    }
-    solve_block(I0, acc0, bpre0, two);
-    if (two) {
-#pragma unroll
-      for (int q = 0; q < 16; q++) { const int e = q * 256 + tid; sW[e / TS][e % TS] = wpre[q]; }
-      accumulate(acc1, tloc, sxl);                       /* sxl complete: solve_block ended with a barrier */
-      solve_block(I1, acc1, bpre1, false);               /* begins with barriers that also cover the sW stores above */
-    }
-    if (t0 == nblk - 1 || (two && t1 == nblk - 1)) {     /* sweep complete: every other block was consumed above */
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(tf, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout,
                          size_t ldb, int nrhs, int mode, int unit, double *d_inv, int inv_ready)
 {
@@ -1323,16 +871,6 @@ static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
   }
   static const bool no_df = getenv("GSL_SINTERP_NO_DATAFLOW_TRSV") && getenv("GSL_SINTERP_NO_DATAFLOW_TRSV")[0] == '1';
   if (use_inv && !no_df && ctx->sk_wgs > 0 && ctx->d_tf && ctx->tf_count >= nblk + 1 && ctx->d_xq) {
-    /* opt-in: measured slower (C3 init 33.1 -> 33.6 ms, C2 2.90 -> 3.00 ms): see the kernel's header */
-    static const bool pairs = getenv("GSL_SINTERP_TRSV_PAIRS") && getenv("GSL_SINTERP_TRSV_PAIRS")[0] == '1';
-    if (pairs && nblk >= 8) {
-      const size_t nunits = (nblk + 1) / 2;
-      const unsigned G2 = (unsigned)(nunits < (size_t)ctx->sk_wgs ? nunits : (size_t)ctx->sk_wgs);
-      hipLaunchKernelGGL(trsv_dataflow_pair_kernel, dim3(G2), dim3(256), 0, ctx->stream, T, ldt, n, (const double *)b, xout, ldb, nrhs,
-                         mode, (const double *)d_inv, ctx->d_tf, ctx->d_xq, (unsigned)nblk);
-      LAUNCH_CHECK(ctx);
-      return ST_SUCCESS;
-    }
     const unsigned G = (unsigned)(nblk < (size_t)ctx->sk_wgs ? nblk : (size_t)ctx->sk_wgs);
     hipLaunchKernelGGL(trsv_dataflow_kernel, dim3(G), dim3(256), 0, ctx->stream, T, ldt, n, (const double *)b, xout, ldb, nrhs, mode,
                        (const double *)d_inv, ctx->d_tf, ctx->d_xq, (unsigned)nblk);

@@ -43,21 +43,10 @@ struct gsl_sinterp_hip_ctx {
   hipStream_t cap_stream;
   struct GraphSlot { hipGraphExec_t exec; size_t n, lda; const void *p0, *p1, *work; } graph[4];
   int use_graphs;
-  /* look-ahead: auxiliary streams (one per recursion depth) and an event pool */
-  hipStream_t la_stream[16];
-  hipEvent_t la_event[4096];
-  int la_events_made, la_events_used, use_lookahead;
   /* stream-K GEMM (gemm.hip): one partial-tile slot + one flag per persistent workgroup */
   double *d_sk_partial;
   unsigned *d_sk_flags;
-  unsigned *d_sk_tiles;     /* XCD super-tile order of the current large update (tile id -> tm, tn) */
   int sk_wgs;               /* persistent workgroups = CUs of the device; 0 = not prepared */
-  /* panel look-ahead of the Cholesky driver (chol.hip): two stream-K launches may be in flight at once -- the bulk
-     update on the side stream, capped at sk_cap workgroups so that the chain's kernels find free CUs, and the small
-     update of the next diagonal block on the main stream, which uses its own partial-tile / flag buffers (sk_alt) */
-  int sk_cap, sk_alt;
-  double *d_sk_partial2;
-  unsigned *d_sk_flags2;
   /* dataflow sweeps (chol.hip): [0] = epoch of the last completed sweep, [1 + J] = epoch in which
      block J was last published.  Never reset (no memset node in the captured graphs): a sweep
      publishes with epoch + 1 and its last block advances the epoch. */
@@ -160,9 +149,6 @@ int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double 
                                int nrhs);
 /* gsl_sinterp_hip_cholesky_decomp1 for an input that is stored symmetrically (both triangles valid) */
 int sinterp_cholesky_decomp1_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info);
-/* chol_dag.hip: the factorisation as one persistent task-DAG launch (n a multiple of 128); *h_done = 0: not run */
-bool sinterp_cholesky_dag_applicable(size_t n, const double *d_a, size_t lda);
-int sinterp_cholesky_dag(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, int *h_done);
 /* second grow-only buffer for vectors that must outlive factorisation workspaces */
 int sinterp_aux(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 int sinterp_invbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);

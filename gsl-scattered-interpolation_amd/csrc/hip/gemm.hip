@@ -40,7 +40,6 @@ struct GemmArgs {
   int lower_only;
   int tiles_m, tiles_n;
   unsigned n_active;   /* tiles that are launched: all, or the lower trapezoid when lower_only */
-  const unsigned *tile_table;   /* stream-K: tile id -> (tm << 16 | tn) in XCD super-tile order, NULL = formula order */
 };
 
 __device__ __forceinline__ double2 ld2(const double *p, bool ok0, bool ok1, bool vec)
@@ -198,8 +197,6 @@ gemm_minus_kernel(GemmArgs g)
    per-lane SOURCE address of the DMA and to the fragment read, so the (row = lane&15,
    k = lane>>4) ds_read_b64 stays bank-conflict free. */
 #define DM_STAGES 3
-#define SK_TILE_TABLE_ENTRIES 262144u   /* tile-order table of the stream-K kernel (1 MiB) */
-#define SK_ALT_WGS 8                    /* workgroups of a launch on the alternate stream-K buffers (look-ahead chain) */
 
 __device__ __forceinline__ void dma16(const double *gsrc, double *ldst)
 {
@@ -397,8 +394,8 @@ __device__ __forceinline__ void decode_tile(const GemmArgs &g, unsigned tile, in
    step is then 16 k-rows of BN doubles, each row one linear 1-KiB DMA wave-instruction (BN = 128), rows pitched
    BN + 16 doubles apart so that the (k = lane>>4, n = lane&15) fragment read -- 16 consecutive doubles per k-row,
    k-rows 32 banks apart -- is conflict-free; no swizzle needed. */
-template <int BM, int BN, int WM, int WN, int SS = 1, int ST = DM_STAGES, bool PIPE = false, bool BKN = false, int WGPC = 1>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, WGPC * (BM / WM) * (BN / WN) / 4 > 0 ? WGPC * (BM / WM) * (BN / WN) / 4 : 1)
+template <int BM, int BN, int WM, int WN, int SS = 1, int ST = DM_STAGES, bool PIPE = false, bool BKN = false>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
 {
   static_assert(ST == 3 || ST == 2, "ring depth");
@@ -440,8 +437,7 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
     int tm, tn;
     {
       const unsigned tid_ = dp ? round * G + gl : dp_tiles + tile;
-      if (g.tile_table) { const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)g.tile_table[tid_]); tm = (int)(e >> 16); tn = (int)(e & 0xffffu); }
-      else decode_tile<BM, BN>(g, tid_, tm, tn);
+      decode_tile<BM, BN>(g, tid_, tm, tn);
     }
     const size_t row0 = (size_t)tm * BM, col0 = (size_t)tn * BN;
 
@@ -702,53 +698,6 @@ gemm_minus_streamk_kernel(GemmArgs g, StreamK x)
   }
 }
 
-/* NEGATIVE RESULT, kept as an opt-in knob (GSL_SINTERP_SUPERTILE=1).  Tile order for the whole-tile rounds of a
-   large update.  In round r the 32 workgroups of an XCD (which share its 4 MiB L2) hold 32 CONSECUTIVE tile ids.
-   With ids running along a tile row those 32 tiles share one A panel but need 32 different B panels: per K-step
-   the XCD pulls (1 x BM + 32 x BN) x 16 doubles through the fabric = 9.7 GB for the 8192^3 launch, which is what
-   the counters show (10.8 GB; algorithmic bytes 1.07 GB).  The idea: let consecutive ids walk SR x SC = 4 x 8
-   SUPER-TILES (row-major inside, super-tiles row by row), so an XCD's 32 tiles need 4 A panels + 8 B panels,
-   (4 BM + 8 BN) x 16 doubles per K-step, 2.1x fewer on paper.  Measured: 12.0 GB and 1 % slower -- the 32-way
-   simultaneous reuse of ONE panel is what the L2 delivers; 4- and 8-way reuse spread over 12 panels is not.  Any shape:
-   tiles outside the (lower-trapezoid) domain are skipped, a prefix sum over the super-tiles gives each its first id.
-   One workgroup; rr = BM / BN. */
-#define ST_SR 4
-#define ST_SC 8
-__global__ void __launch_bounds__(1024)
-gemm_tile_order_kernel(int tiles_m, int tiles_n, int lower_only, unsigned rr, unsigned *__restrict__ table)
-{
-  __shared__ unsigned s_cnt[1024];
-  const int sup_m = (tiles_m + ST_SR - 1) / ST_SR, sup_n = (tiles_n + ST_SC - 1) / ST_SC;
-  const int nsup = sup_m * sup_n, t = threadIdx.x;
-  auto valid = [&](int tm, int tn) -> bool {
-    if (tm >= tiles_m || tn >= tiles_n) return false;
-    if (!lower_only) return true;
-    const unsigned lim = rr * (unsigned)(tm + 1);                     /* row tm of tiles holds min(rr (tm+1), tiles_n) tiles */
-    return (unsigned)tn < (lim < (unsigned)tiles_n ? lim : (unsigned)tiles_n);
-  };
-  unsigned cnt = 0;
-  const int sm = t / sup_n, sn = t % sup_n;
-  if (t < nsup)
-    for (int a = 0; a < ST_SR; a++)
-      for (int b = 0; b < ST_SC; b++) cnt += valid(sm * ST_SR + a, sn * ST_SC + b);
-  s_cnt[t] = cnt;
-  __syncthreads();
-  /* exclusive scan over <= 1024 entries (Hillis-Steele; one launch per large update, off the critical path) */
-  for (int off = 1; off < 1024; off <<= 1) {
-    const unsigned v = t >= off ? s_cnt[t - off] : 0u;
-    __syncthreads();
-    s_cnt[t] += v;
-    __syncthreads();
-  }
-  unsigned pos = s_cnt[t] - cnt;
-  if (t < nsup)
-    for (int a = 0; a < ST_SR; a++)
-      for (int b = 0; b < ST_SC; b++) {
-        const int tm = sm * ST_SR + a, tn = sn * ST_SC + b;
-        if (valid(tm, tn)) table[pos++] = ((unsigned)tm << 16) | (unsigned)tn;
-      }
-}
-
 int sinterp_streamk_prepare(gsl_sinterp_hip_ctx *ctx)
 {
   if (ctx->sk_wgs) return ST_SUCCESS;
@@ -759,11 +708,7 @@ int sinterp_streamk_prepare(gsl_sinterp_hip_ctx *ctx)
   if (cus <= 0) return ST_SUCCESS;
   HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_partial, (size_t)cus * 256 * GT_BN * sizeof(double)));
   HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_flags, (size_t)cus * 2 * sizeof(unsigned)));   /* 2 x: the two-workgroups-per-CU variant */
-  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_tiles, SK_TILE_TABLE_ENTRIES * sizeof(unsigned)));
   HIP_OK(ctx, hipMemset(ctx->d_sk_flags, 0, (size_t)cus * 2 * sizeof(unsigned)));
-  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_partial2, (size_t)SK_ALT_WGS * 256 * GT_BN * sizeof(double)));
-  HIP_OK(ctx, hipMalloc((void **)&ctx->d_sk_flags2, (size_t)SK_ALT_WGS * sizeof(unsigned)));
-  HIP_OK(ctx, hipMemset(ctx->d_sk_flags2, 0, (size_t)SK_ALT_WGS * sizeof(unsigned)));
   HIP_OK(ctx, hipDeviceSynchronize());
   ctx->sk_wgs = cus;
   return ST_SUCCESS;
@@ -847,7 +792,6 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   GemmArgs g;
   g.m = m; g.n = n; g.k = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.lower_only = lower_only;
-  g.tile_table = NULL;
   g.tiles_m = (int)((m + GT_BM - 1) / GT_BM);
   g.tiles_n = (int)((n + GT_BN - 1) / GT_BN);
   if (lower_only && g.tiles_m < g.tiles_n) g.tiles_n = g.tiles_m;   /* columns right of the square part are all above the diagonal */
@@ -876,12 +820,12 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
   static const bool no_dma = getenv("GSL_SINTERP_NO_DMA_GEMM") && getenv("GSL_SINTERP_NO_DMA_GEMM")[0] == '1';
   if (full && !b_is_kn && k >= 4 * GT_BK && !no_dma) {
     static const bool no_w8 = getenv("GSL_SINTERP_NO_GEMM8") && getenv("GSL_SINTERP_NO_GEMM8")[0] == '1';
-    if (ctx->sk_wgs > 0 && !ctx->use_lookahead) {
+    if (ctx->sk_wgs > 0) {
       /* stream-K: G persistent workgroups share the (tile, K-step) space evenly */
       StreamK x;
       x.steps = (unsigned)(k / GT_BK);                   /* groups per tile; rescaled below for the grouped 64x64 variant */
-      x.partial = ctx->sk_alt ? ctx->d_sk_partial2 : ctx->d_sk_partial;
-      x.flags = ctx->sk_alt ? ctx->d_sk_flags2 : ctx->d_sk_flags;
+      x.partial = ctx->d_sk_partial;
+      x.flags = ctx->d_sk_flags;
       GemmArgs h = g;
       unsigned tiles = grid;
       int cfg = 1;                                       /* 0: 256x128, 1: 128x128, 2: 64x64 */
@@ -909,8 +853,7 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       /* developer override (tools/gemm_cfg_sweep.py): force the tile configuration where the shape allows it */
       if (getenv("GSL_SINTERP_GEMM_CFG")) {
         const int want_cfg = atoi(getenv("GSL_SINTERP_GEMM_CFG"));
-        if (want_cfg == 3 || want_cfg == 4) { cfg = want_cfg; h = g; tiles = grid; }
-        else if (want_cfg == 1 || (want_cfg == 2 && m % 64 == 0 && n % 64 == 0)) {
+        if (want_cfg == 1 || (want_cfg == 2 && m % 64 == 0 && n % 64 == 0)) {
           cfg = want_cfg; h = g; tiles = grid;
           if (want_cfg == 2) {
             h.tiles_m = (int)(m / 64); h.tiles_n = (int)(n / 64);
@@ -926,42 +869,17 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
       unsigned long long total64 = (unsigned long long)tiles * x.steps;
       unsigned long long want = total64 / (grouped ? 4 : 16);   /* >= 16 K-steps (of 16) per workgroup ... */
       if (want < tiles) want = tiles;                     /* ... but never fewer workgroups than tiles */
-      unsigned long long wg_cap = (unsigned long long)ctx->sk_wgs * ((cfg == 3 || cfg == 4) ? 2 : 1);
-      if (ctx->sk_cap > 0 && (unsigned long long)ctx->sk_cap < wg_cap) wg_cap = (unsigned long long)ctx->sk_cap;
-      if (ctx->sk_alt && wg_cap > SK_ALT_WGS) wg_cap = SK_ALT_WGS;
+      const unsigned long long wg_cap = (unsigned long long)ctx->sk_wgs;
       if (want > wg_cap) want = wg_cap;
       const unsigned G = (unsigned)(want ? want : 1);
       /* many tiles: all but the last full round (and the remainder) as whole tiles */
       static const bool no_hybrid = getenv("GSL_SINTERP_NO_HYBRID_SK") && getenv("GSL_SINTERP_NO_HYBRID_SK")[0] == '1';
       x.dp_rounds = (!no_hybrid && tiles / G >= 2) ? tiles / G - 1 : 0;
       total64 = (unsigned long long)(tiles - x.dp_rounds * G) * x.steps;
-      h.tile_table = NULL;
-      /* opt-in: measured on MI355X (rocprofv3 FETCH_SIZE, 8192^3 lower): 12.0 GB through the fabric with the super-tile
-         order against 10.8 GB with ids running along tile rows, and 1 % slower -- the model below does not hold */
-      static const bool use_super = getenv("GSL_SINTERP_SUPERTILE") && getenv("GSL_SINTERP_SUPERTILE")[0] == '1';
-      if (use_super && x.dp_rounds >= 1 && cfg != 2 && ctx->d_sk_tiles && tiles <= SK_TILE_TABLE_ENTRIES && h.tiles_m < 65536 &&
-          h.tiles_n < 65536 && ((h.tiles_m + ST_SR - 1) / ST_SR) * ((h.tiles_n + ST_SC - 1) / ST_SC) <= 1024) {
-        hipLaunchKernelGGL(gemm_tile_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, h.tiles_m, h.tiles_n, lower_only,
-                           cfg == 0 ? 2u : 1u, ctx->d_sk_tiles);
-        h.tile_table = ctx->d_sk_tiles;
-      }
       if (total64 < 0x7fffffffull) {
       x.total = (unsigned)total64; x.base = x.total / G; x.rem = x.total % G;
       static const bool no_pipe = getenv("GSL_SINTERP_NO_GEMM_PIPE") && getenv("GSL_SINTERP_NO_GEMM_PIPE")[0] == '1';
-      if (cfg == 3) {
-        /* EXPERIMENT (GSL_SINTERP_GEMM_CFG=3): 128 x 128 tiles, TWO workgroups per CU on a two-deep ring (64 KiB each):
-           the waves of one workgroup wait at their barrier while the other workgroup's waves feed the matrix pipe */
-        const size_t lds = (size_t)2 * (128 + 128) * GT_BK * sizeof(double);
-        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<128, 128, 64, 64, 1, 2, false, false, 2>, (int)lds); if (ast) return ast; }
-        hipLaunchKernelGGL((gemm_minus_streamk_kernel<128, 128, 64, 64, 1, 2, false, false, 2>), dim3(G), dim3(256), lds, ctx->stream, h, x);
-      } else if (cfg == 4) {
-        /* EXPERIMENT (GSL_SINTERP_GEMM_CFG=4): the same with two 16-wide sub-steps per barrier pair (128 KiB for two workgroups) */
-        const size_t lds = (size_t)2 * 2 * (128 + 128) * GT_BK * sizeof(double);
-        x.steps = (unsigned)(k / (2 * GT_BK));
-        { unsigned long long t64 = (unsigned long long)(tiles - x.dp_rounds * G) * x.steps; x.total = (unsigned)t64; x.base = x.total / G; x.rem = x.total % G; }
-        { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<128, 128, 64, 64, 2, 2, false, false, 2>, (int)lds); if (ast) return ast; }
-        hipLaunchKernelGGL((gemm_minus_streamk_kernel<128, 128, 64, 64, 2, 2, false, false, 2>), dim3(G), dim3(256), lds, ctx->stream, h, x);
-      } else if (cfg == 0 && !no_pipe) {
+      if (cfg == 0 && !no_pipe) {
         const size_t lds = (size_t)DM_STAGES * (256 + 128) * GT_BK * sizeof(double);
         { int ast = sinterp_func_lds(ctx, (const void *)gemm_minus_streamk_kernel<256, 128, 64, 64, 1, 3, true>, (int)lds); if (ast) return ast; }
         hipLaunchKernelGGL((gemm_minus_streamk_kernel<256, 128, 64, 64, 1, 3, true>), dim3(G), dim3(512), lds, ctx->stream, h, x);
@@ -1013,7 +931,7 @@ int sinterp_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, size_t k, c
     return ST_SUCCESS;
   }
   static const bool no_kn = getenv("GSL_SINTERP_NO_KN_STREAMK") && getenv("GSL_SINTERP_NO_KN_STREAMK")[0] == '1';
-  if (b_is_kn && full && !lower_only && !no_dma && !no_kn && ctx->sk_wgs > 0 && !ctx->use_lookahead && k >= 4 * GT_BK) {
+  if (b_is_kn && full && !lower_only && !no_dma && !no_kn && ctx->sk_wgs > 0 && k >= 4 * GT_BK) {
     /* C -= A B with B stored [k][n] (the N.N updates of the LU route): the stream-K DMA pipeline with a [k][n] B image */
     StreamK x;
     x.steps = (unsigned)(k / GT_BK);

@@ -32,12 +32,6 @@ extern "C" int gsl_sinterp_hip_ctx_create(gsl_sinterp_hip_ctx **out, int device,
     const char *e = getenv("GSL_SINTERP_NO_GRAPH");
     ctx->use_graphs = !(e && e[0] == '1');
   }
-  {
-    /* measured on MI355X: no gain (the panel kernels queue behind multi-ms GEMM tiles unless CUs
-       are partitioned), so look-ahead is opt-in */
-    const char *e = getenv("GSL_SINTERP_LOOKAHEAD");
-    ctx->use_lookahead = (e && e[0] == '1');
-  }
   ctx->scratch_bytes = 4096;
   if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipMalloc(&ctx->d_scratch, ctx->scratch_bytes) != hipSuccess) {
@@ -70,8 +64,6 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   for (int i = 0; i < 4; i++)
     if (ctx->graph[i].exec) (void)hipGraphExecDestroy(ctx->graph[i].exec);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
-  for (int i = 0; i < 16; i++) if (ctx->la_stream[i]) (void)hipStreamDestroy(ctx->la_stream[i]);
-  for (int i = 0; i < ctx->la_events_made; i++) (void)hipEventDestroy(ctx->la_event[i]);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
@@ -84,9 +76,6 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->d_sk_partial) (void)hipFree(ctx->d_sk_partial);
   if (ctx->d_sk_flags) (void)hipFree(ctx->d_sk_flags);
-  if (ctx->d_sk_partial2) (void)hipFree(ctx->d_sk_partial2);
-  if (ctx->d_sk_flags2) (void)hipFree(ctx->d_sk_flags2);
-  if (ctx->d_sk_tiles) (void)hipFree(ctx->d_sk_tiles);
   if (ctx->d_tf) (void)hipFree(ctx->d_tf);
   if (ctx->d_xq) (void)hipFree(ctx->d_xq);
   if (ctx->d_jumpt) (void)hipFree(ctx->d_jumpt);

@@ -195,19 +195,52 @@ simplex_tree *simplex_tree_fread(FILE *stream)
   if (fread(head, sizeof head[0], 6, stream) != 6 || head[0] != 1)
     GSL_ERROR_NULL("simplex_tree_fread: unsupported checkpoint version", GSL_EFAILED);
   const int dim = head[1], n = head[2], n_points = head[3], max_points = head[4];
-  /* a triangulation of p points has at most 9p + 8 history nodes here (alloc's own estimate, linear_simplex.c:63):
-     an 8-byte corrupt header must not turn into gigabytes of node_alloc or an int overflow in 9 * max_points */
-  if (dim != 2 || n < 1 || n_points < 0 || max_points < n_points || max_points > INT_MAX / 27 ||
-      (long long)n > 9LL * max_points + 8)
+  /* No bound of n in terms of the point count: 9 nodes per point is alloc's average-case preallocation
+     (linear_simplex.c:63, doubled on demand), and un-shuffled or sorted inputs build far longer histories (a sorted
+     parabola of 200 points: 40 287 nodes).  What guards against a corrupt 8-byte header is the stream itself: the
+     node types are read first, in bounded chunks, so memory only grows with what the file really holds, and the
+     node arrays are allocated once n types have arrived. */
+  if (dim != 2 || n < 1 || n_points < 0 || max_points < n_points || max_points > INT_MAX / 27 || n > INT_MAX / (4 * (dim + 1)))
     GSL_ERROR_NULL("simplex_tree_fread: corrupt header", GSL_EFAILED);
+  {
+    /* seekable stream: the counts must fit what is left of the file (types + vertex ids + links + geometry + shuffle) */
+    const long here = ftell(stream);
+    if (here >= 0 && fseek(stream, 0L, SEEK_END) == 0) {
+      const long end = ftell(stream);
+      const long long need = 4LL * n + 8LL * (dim + 1) * n + 14 * 8 + 8LL * max_points;
+      if (fseek(stream, here, SEEK_SET) != 0) GSL_ERROR_NULL("simplex_tree_fread: stream error", GSL_EFAILED);
+      if (end >= here && (long long)(end - here) < need)
+        GSL_ERROR_NULL("simplex_tree_fread: short or corrupt checkpoint", GSL_EFAILED);
+    }
+  }
+  int ok = 1;
+  int32_t *type = NULL;
+  {
+    size_t have = 0, cap = 0;
+    while (ok && have < (size_t)n) {
+      size_t want = (size_t)n - have;
+      if (want > ((size_t)1 << 20)) want = (size_t)1 << 20;
+      if (have + want > cap) {
+        cap = cap ? 2 * cap : want;
+        if (cap > (size_t)n) cap = (size_t)n;
+        if (cap < have + want) cap = have + want;
+        int32_t *grown = (int32_t *)realloc(type, cap * sizeof(int32_t));
+        if (!grown) { ok = 0; break; }
+        type = grown;
+      }
+      ok = fread(type + have, sizeof(int32_t), want, stream) == want;
+      have += want;
+    }
+  }
+  if (!ok) {
+    free(type);
+    GSL_ERROR_NULL("simplex_tree_fread: short or corrupt checkpoint", GSL_EFAILED);
+  }
   simplex_tree *tree = simplex_tree_alloc(dim, max_points);
-  if (!tree) return NULL;
+  if (!tree) { free(type); return NULL; }
   /* make room for n nodes (alloc preallocates 9 per point and doubles on demand, linear_simplex.c:23-46) */
   while (tree->n_simplexes < n)
-    if (simplex_tree_node_alloc(tree) < 0) { simplex_tree_free(tree); return NULL; }
-  int ok = 1;
-  int32_t *type = (int32_t *)malloc((size_t)n * sizeof(int32_t));
-  ok = ok && type && fread(type, sizeof(int32_t), (size_t)n, stream) == (size_t)n;
+    if (simplex_tree_node_alloc(tree) < 0) { free(type); simplex_tree_free(tree); return NULL; }
   const size_t w = (size_t)(dim + 1) * (size_t)n;
   ok = ok && fread(tree->pidx, sizeof(int), w, stream) == w;
   ok = ok && fread(tree->links, sizeof(simplex_index), w, stream) == w;

@@ -75,21 +75,24 @@ static inline const double *vertex_xy(const simplex_tree *tree, const gsl_matrix
 simplex_index simplex_tree_node_alloc(simplex_tree *tree)
 {
   const int dim = tree->dim;
+  /* grow by doubling (linear_simplex.c:318-329); the old block stays valid and owned by the tree when realloc fails */
   if (tree->n_simplexes + 1 >= tree->max_simplexes) {
+    simplex_tree_node *grown = (simplex_tree_node *)realloc(tree->simplexes, 2 * (size_t)tree->max_simplexes * sizeof(simplex_tree_node));
+    if (!grown) { gsl_error("out of memory growing simplex tree", __FILE__, __LINE__, GSL_ENOMEM); return -1; }
+    tree->simplexes = grown;
     tree->max_simplexes *= 2;
-    tree->simplexes = (simplex_tree_node *)realloc(tree->simplexes, (size_t)tree->max_simplexes * sizeof(simplex_tree_node));
   }
   if (tree->n_pidx + dim + 1 >= tree->max_pidx) {
+    int *grown = (int *)realloc(tree->pidx, 2 * (size_t)tree->max_pidx * sizeof(int));
+    if (!grown) { gsl_error("out of memory growing simplex tree", __FILE__, __LINE__, GSL_ENOMEM); return -1; }
+    tree->pidx = grown;
     tree->max_pidx *= 2;
-    tree->pidx = (int *)realloc(tree->pidx, (size_t)tree->max_pidx * sizeof(int));
   }
   if (tree->n_links + dim + 1 >= tree->max_links) {
+    simplex_index *grown = (simplex_index *)realloc(tree->links, 2 * (size_t)tree->max_links * sizeof(simplex_index));
+    if (!grown) { gsl_error("out of memory growing simplex tree", __FILE__, __LINE__, GSL_ENOMEM); return -1; }
+    tree->links = grown;
     tree->max_links *= 2;
-    tree->links = (simplex_index *)realloc(tree->links, (size_t)tree->max_links * sizeof(simplex_index));
-  }
-  if (!tree->simplexes || !tree->pidx || !tree->links) {
-    gsl_error("out of memory growing simplex tree", __FILE__, __LINE__, GSL_ENOMEM);
-    return -1;
   }
   simplex_tree_node *node = &tree->simplexes[tree->n_simplexes];
   node->points = tree->n_pidx;

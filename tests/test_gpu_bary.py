@@ -357,32 +357,6 @@ def test_large_batch_values_only_and_strided_targets(pkg, orc):
     assert np.array_equal(bits(d_v2.cpu().numpy()), bits(ovals))
 
 
-def test_chunked_two_stream_pipeline_changes_no_bit(pkg, orc, monkeypatch):
-    """Round 3 (opt-in, measured slower: DESIGN 6): with GSL_SINTERP_BARY_CHUNKS=1 a large batch is cut into four pieces
-    that alternate between the context's stream and its side stream (chunk i+1 is binned while chunk i walks).  A value
-    depends on (records, target) only: chunked = one piece, bit for bit, ragged sizes and NaN / outside targets
-    included; GSL_SINTERP_BARY_CHUNK_MIN lowers the size at which the split starts so that the path runs at test size."""
-    n, m = 6000, 301_003
-    x = orc.synth_centres(n, 2)
-    f = orc.synth_response(x)
-    y = orc.synth_targets(0, m, 2)
-    y[1234] = [np.nan, 0.3]
-    y[-7:] += 1e6                                              # outside the cage
-    t, o = build_pair(pkg, orc, x)
-    d = t.device_alloc(0)
-    assert d.set_response(f) == 0
-    st0, v0, l0 = d.eval_many(y)
-    monkeypatch.setenv("GSL_SINTERP_BARY_CHUNKS", "1")
-    monkeypatch.setenv("GSL_SINTERP_BARY_CHUNK_MIN", "20000")
-    for rep in range(2):                                       # twice: the sections are reused
-        st1, v1, l1 = d.eval_many(y)
-        assert st0 == st1 == pkg.GSL_EDOM
-        assert np.array_equal(l0, l1) and np.array_equal(bits(v0), bits(v1))
-    idx = np.arange(0, m, 53)
-    ov, ol = o.eval_many(x, f, np.ascontiguousarray(y[idx]))
-    assert np.array_equal(l1[idx], ol) and np.array_equal(bits(v1[idx]), bits(ov))
-
-
 @pytest.mark.parametrize("shape", ["uniform", "cluster_plus_sparse_background"])
 def test_two_level_reorder_matches_one_level_and_oracle(pkg, orc, monkeypatch, shape):
     """Round 3: batches of >= 2^18 targets are ordered by the two-level reorder of sort.hip (coarse bins by LDS

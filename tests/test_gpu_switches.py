@@ -18,11 +18,9 @@ BARY = ["tests/test_gpu_bary.py"]
 
 CASES = [
     ("GSL_SINTERP_NO_GRAPH", LINALG), ("GSL_SINTERP_NO_GRAPH", RBF_INIT),
-    ("GSL_SINTERP_NO_STREAMK", LINALG), ("GSL_SINTERP_NO_HYBRID_SK", LINALG), ("GSL_SINTERP_NO_GEMM8", LINALG), ("GSL_SINTERP_NO_GEMM64", LINALG), ("GSL_SINTERP_NO_GEMM_GROUP", LINALG), ("GSL_SINTERP_NO_GEMM_PIPE", LINALG), ("GSL_SINTERP_NO_KN_STREAMK", LINALG), ("GSL_SINTERP_SUPERTILE", LINALG),
+    ("GSL_SINTERP_NO_STREAMK", LINALG), ("GSL_SINTERP_NO_HYBRID_SK", LINALG), ("GSL_SINTERP_NO_GEMM8", LINALG), ("GSL_SINTERP_NO_GEMM64", LINALG), ("GSL_SINTERP_NO_GEMM_GROUP", LINALG), ("GSL_SINTERP_NO_GEMM_PIPE", LINALG), ("GSL_SINTERP_NO_KN_STREAMK", LINALG),
     ("GSL_SINTERP_NO_DMA_GEMM", LINALG), ("GSL_SINTERP_NO_PANEL128", LINALG), ("GSL_SINTERP_NO_PANEL128", RBF_INIT),
-    ("GSL_SINTERP_NO_DATAFLOW_TRSV", LINALG), ("GSL_SINTERP_NO_DATAFLOW_TRSV", RBF_INIT), ("GSL_SINTERP_TRSV_PAIRS", LINALG),
-    ("GSL_SINTERP_LOOKAHEAD", LINALG), ("GSL_SINTERP_PANEL_LA", LINALG), ("GSL_SINTERP_PANEL_LA", RBF_INIT),
-    ("GSL_SINTERP_CHOL_DAG", LINALG), ("GSL_SINTERP_CHOL_DAG", RBF_INIT),
+    ("GSL_SINTERP_NO_DATAFLOW_TRSV", LINALG), ("GSL_SINTERP_NO_DATAFLOW_TRSV", RBF_INIT),
     ("GSL_SINTERP_NO_SORT", RBF_SWEEP), ("GSL_SINTERP_NO_CULL", RBF_SWEEP), ("GSL_SINTERP_SERIAL_CELL_ORDER", RBF_SWEEP),
     ("GSL_SINTERP_SORT_LEVELS", BARY), ("GSL_SINTERP_SORT_LEVELS", RBF_SWEEP),      # "1": the one-level (atomic) target sort for every batch size
     ("GSL_SINTERP_NO_SORT", BARY), ("GSL_SINTERP_NO_JUMP", BARY), ("GSL_SINTERP_NO_FASTDIV", BARY), ("GSL_SINTERP_NO_AFFINE_WALK", BARY), ("GSL_SINTERP_NO_SIDE_STREAM", BARY),

@@ -91,6 +91,28 @@ def test_tree_checkpoint_round_trip(pkg, orc, tmp_path):
     assert pkg.SimplexTree.fread(tmp_path / "corrupt.bin") is None
 
 
+def test_tree_checkpoint_round_trips_long_histories(pkg, orc, tmp_path):
+    """9 nodes per point is alloc's average-case preallocation (linear_simplex.c:63), not a bound.  Points on a
+    parabola inserted in sorted order without a shuffle (rng = NULL, the facade's default) flip almost every earlier edge:
+    the history DAG has far more than 9 * n + 8 nodes, and simplex_tree_fread must still read back what fwrite wrote."""
+    n = 200
+    u = np.linspace(1.0, 0.0, n)
+    x = np.ascontiguousarray(np.stack([u, u * u], axis=1))
+    t = pkg.SimplexTree(2, n)
+    assert t.init(x, flags=0, rng=None) == 0
+    assert t.n_nodes > 9 * n + 8, t.n_nodes
+    path = tmp_path / "long.bin"
+    assert t.fwrite(path) == 0
+    t2 = pkg.SimplexTree.fread(path, data=x)
+    assert t2 is not None and t2.n_nodes == t.n_nodes
+    for a, b in zip(t.arrays(), t2.arrays()):
+        assert np.array_equal(a, b)
+    f = orc.synth_response(x)
+    for p in ([0.5, 0.3], [0.2, 0.1], [0.9, 0.85]):
+        la, lb = t.find_leaf(np.array(p)), t2.find_leaf(np.array(p))
+        assert la == lb and t.interp_point(la, f, np.array(p)) == t2.interp_point(lb, f, np.array(p))
+
+
 def test_tree_checkpoint_rejects_corrupt_headers_and_links(pkg, orc, tmp_path):
     """simplex_tree_fread bounds the header counts (no multi-GB allocation / int overflow from 8 corrupt
     bytes), requires the shuffle to be a permutation and child links to point forward (acyclic DAG)."""
@@ -113,7 +135,7 @@ def test_tree_checkpoint_rejects_corrupt_headers_and_links(pkg, orc, tmp_path):
         except pkg.capi.GslError:
             return None
     assert load(raw) is not None
-    for field, value in ((2, 2**31 - 1), (4, 2**31 - 1), (4, 2**31 // 9 + 5), (2, 9 * head[4] + 9)):
+    for field, value in ((2, 2**31 - 1), (4, 2**31 - 1), (4, 2**31 // 9 + 5), (4, 2**31 // 27 - 5), (2, 9 * head[4] + 9), (2, 10 * nn)):
         bad = bytearray(raw)
         h = list(head); h[field] = value
         struct.pack_into("<6i", bad, 8, *h)
