@@ -29,6 +29,8 @@ extern "C" int gsl_sinterp_hip_debug_diag_ts(unsigned long long *out) { return (
 #endif
 #include "chol_potrf.h"
 
+#define TRSV_MAXR 5   /* right-hand sides solved together (f + the d+1 polynomial columns) */
+
 
 /* ------------------------------------------------------------------------ */
 /* base: factor the nb x nb diagonal block (nb <= 32) and solve the rows below */
@@ -146,13 +148,60 @@ chol_diag_writeback_kernel(double *__restrict__ A, size_t lda, size_t n, const d
    LDS layout of triangles: packed 32x32 blocks of pitch 34 doubles -- 34 = 2 mod 4 makes the
    (row = lane&15, k = lane>>4) MFMA fragment reads conflict free. */
 
+/* Forward substitution folded into the factorisation (round 4).  With right-hand sides f (nrhs vectors, fb + q * ldf),
+   the driver keeps them "one panel ahead": when panel p is factored, f_p (rows j0 .. j0+127) already carries the updates of
+   every earlier panel, so  y_p = L_pp^-1 f_p  is final (cblas/source_trsv_r.h:56-79 computes the same sums row by row);
+   chol_trsm16_kernel then subtracts L[R, p] y_p from the entries below.  After the last panel fb holds L^-1 f and the
+   solve only needs its backward sweep.  Here: block substitution with the inverted 32 x 32 diagonal blocks that the
+   factorisation leaves in Dv, one right-hand side per wave (wave-local: no workgroup barrier), lanes = 32 rows x 2 halves
+   of the K range. */
+__device__ __forceinline__ void diag128_forward(const double *S, const double *Dv, double *fs, double *tt, int tid, int nrhs)
+{
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+  for (int q = wave; q < nrhs; q += 4) {
+    double *y = fs + q * PB, *t = tt + q * CB;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      double sum = 0.0;
+#pragma unroll
+      for (int kb = 0; kb < i; kb++) {
+        const double *Lr = S + pblk(i, kb) + r * PQ + half * 16;
+        const double *yk = y + kb * 32 + half * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+          const double2 l2 = *reinterpret_cast<const double2 *>(Lr + k);
+          sum = fma(l2.x, yk[k], sum);
+          sum = fma(l2.y, yk[k + 1], sum);
+        }
+      }
+      sum += __shfl_xor(sum, 32);
+      if (half == 0) t[r] = y[i * 32 + r] - sum;
+      __builtin_amdgcn_wave_barrier();
+      /* y_i = Dinv_i t  (Dinv lower triangular: exact zeros above the diagonal) */
+      const double *Wr = Dv + i * PBLK + r * PQ + half * 16;
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+        const double2 w2 = *reinterpret_cast<const double2 *>(Wr + c);
+        acc = fma(w2.x, t[half * 16 + c], acc);
+        acc = fma(w2.y, t[half * 16 + c + 1], acc);
+      }
+      acc += __shfl_xor(acc, 32);
+      if (half == 0) y[i * 32 + r] = acc;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restrict__ info, double *__restrict__ diag_store,
-                    double *__restrict__ Dinvg)
+                    double *__restrict__ Dinvg, double *__restrict__ fb, size_t ldf, int nrhs)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *S = sm;                       /* 10 packed blocks of the lower triangle */
   double *Dv = S + 10 * PBLK;           /* 4 blocks: inverses of the diagonal blocks */
+  double *fs = Dv + 4 * PBLK;           /* [TRSV_MAXR][128] right-hand sides of the folded forward substitution */
+  double *tt = fs + 5 * PB;             /* [TRSV_MAXR][32] */
   const int tid = threadIdx.x;
   double *Ab = A + j0 * lda + j0;
   TSTAMP(0);
@@ -160,7 +209,7 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
   /* load the lower triangle (whole 32x32 blocks, coalesced along k): all 40 loads of a thread are
      issued before the first LDS store (one memory round trip, not 40) */
   {
-    double v[40];
+    double v[40], fv[3];
     const int r8 = tid >> 5, k = tid & 31;
 #pragma unroll
     for (int t = 0; t < 40; t++) {
@@ -169,7 +218,11 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
       v[t] = Ab[(size_t)(BI[b] * 32 + r) * lda + BJ[b] * 32 + k];
     }
 #pragma unroll
+    for (int t = 0; t < 3; t++) { const int e = t * 256 + tid; fv[t] = e < nrhs * PB ? fb[(size_t)(e >> 7) * ldf + j0 + (e & 127)] : 0.0; }
+#pragma unroll
     for (int t = 0; t < 40; t++) S[(t >> 2) * PBLK + ((t & 3) * 8 + r8) * PQ + k] = v[t];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { const int e = t * 256 + tid; if (e < nrhs * PB) fs[e] = fv[t]; }
   }
   __syncthreads();
   TSTAMP(1);
@@ -177,6 +230,10 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
   potrf128_lds<4>(S, Dv, tid, info, j0);
 
   TSTAMP(18);
+  if (nrhs > 0) {
+    diag128_forward(S, Dv, fs, tt, tid, nrhs);
+    __syncthreads();
+  }
   /* L -> A (lower part only); the diagonal 32-blocks also -> diag_store in the format of
      chol_base_kernel, so that chol_diag_writeback_kernel rewrites the same values */
   {
@@ -194,26 +251,196 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
       const int b = t >> 2, r = (t & 3) * 8 + r8;
       Dinvg[b * 1024 + r * 32 + k] = Dv[b * PBLK + r * PQ + k];
     }
+#pragma unroll
+    for (int t = 0; t < 3; t++) { const int e = t * 256 + tid; if (e < nrhs * PB) fb[(size_t)(e >> 7) * ldf + j0 + (e & 127)] = fs[e]; }
   }
   TSTAMP(19);
 }
 
-/* rows below a 128-wide diagonal block: X = B L^-T in place.  64 rows per workgroup, wave w owns rows
-   16w..16w+15 for all four 32-column steps, so the steps need no workgroup barrier. */
+/* rows below a 128-wide diagonal block: X = B L^-T in place (round 4).
+   Block substitution over the four 32-column blocks c:   Y_c = B_c - sum_{p<c} X_p L_cp^T,   X_c = Y_c Dinv_c^T.
+   The round-2 kernel gave every wave a 16-row strip for all 128 columns: 144 dependent MFMAs per wave (3.8 us) whatever
+   the height of the panel, and its 64 rows per workgroup left most CUs idle below ~16 k rows.  Here a workgroup owns
+   16 RF rows, RF chosen by the driver so that the launch is about one workgroup per CU:
+     RF = 1 (panels up to 4 k rows): the four waves split every product as (f, h) = (16-column fragment of the block, half
+             of the K range); the partial sums meet in LDS and are added when read back as A operands -- 32 / 40 MFMAs per wave;
+     RF = 2, 4: wave (f, g) owns the row fragments g, g + 2 with the whole K range (no partial sums), 80 MFMAs per row fragment.
+   7 workgroup barriers.  Every operand that does not depend on an earlier step (B tile, the L blocks and Dinv blocks as MFMA
+   B fragments) is fetched from global / L2 straight into registers at kernel start: one memory round trip, no LDS staging
+   (with 16 rows per workgroup at 16 k rows those fragment loads alone were 83 MB per launch: hence RF).
+   Folded forward substitution (nrhs > 0, see diag128_forward): f[R] -= X_R y_p while X_R passes through LDS on its way out. */
+#define TRX 130
+#define TRY 34
+template <int RF>
 __global__ void __launch_bounds__(256)
-chol_trsm128_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, const double *__restrict__ Dinvg, size_t row_start)
+chol_trsm16_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, const double *__restrict__ Dinvg, size_t row_start,
+                   double *__restrict__ fb, size_t ldf, int nrhs)
+{
+  constexpr bool KSPLIT = RF == 1;
+  constexpr int NP = KSPLIT ? 2 : 1;              /* planes of partial sums */
+  constexpr int NRF = KSPLIT ? 1 : RF / 2;        /* row fragments per wave */
+  constexpr int ROWS = 16 * RF;
+  constexpr int LCH = KSPLIT ? 4 : 8;             /* K chunks (of 4) per 32-wide block in the L products */
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *Xp = sm;                                /* [NP][ROWS][TRX] */
+  double *Yp = Xp + NP * ROWS * TRX;              /* [NP][ROWS][TRY] */
+  double *ys = Yp + NP * ROWS * TRY;              /* [TRSV_MAXR][PB] */
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = wave & 1, g = wave >> 1, fr = lane & 15, fq = lane >> 4;
+  const int plane = KSPLIT ? g : 0;
+  const size_t row0 = row_start + (size_t)blockIdx.x * ROWS;
+  const int dch = KSPLIT ? (f ? 4 : 2) : (f ? 8 : 4);       /* K chunks of this wave in the Dinv products: K = 16 (f + 1) */
+  const int dk0 = KSPLIT ? dch * g : 0, lk0 = KSPLIT ? 4 * g : 0;
+
+  /* ---- every global load of the kernel, issued before the first use */
+  double a0[NRF][8], dv[4][8], lb[6][LCH], yv[3];
+  double4_t cinit[NRF][3];
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) dv[c][i] = i < dch ? Dinvg[c * 1024 + (16 * f + fr) * 32 + 4 * (dk0 + i) + fq] : 0.0;
+#pragma unroll
+  for (int c = 1; c < 4; c++)
+#pragma unroll
+    for (int p = 0; p < c; p++)
+#pragma unroll
+      for (int i = 0; i < LCH; i++)
+        lb[c * (c - 1) / 2 + p][i] = A[(j0 + 32 * c + 16 * f + fr) * lda + j0 + 32 * p + 4 * (lk0 + i) + fq];
+#pragma unroll
+  for (int t = 0; t < NRF; t++) {
+    const int rf = KSPLIT ? 0 : g + 2 * t;
+    const size_t arow = row0 + 16 * rf + fr < n ? row0 + 16 * rf + fr : n - 1;
+    const double *Arow = A + arow * lda + j0;               /* this lane's row as MFMA A operand */
+#pragma unroll
+    for (int i = 0; i < 8; i++) a0[t][i] = i < dch ? Arow[4 * (dk0 + i) + fq] : 0.0;
+#pragma unroll
+    for (int c = 1; c < 4; c++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const size_t r = row0 + 16 * rf + fq + 4 * rg < n ? row0 + 16 * rf + fq + 4 * rg : n - 1;
+        cinit[t][c - 1][rg] = plane == 0 ? A[r * lda + j0 + 32 * c + 16 * f + fr] : 0.0;
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; t++) { const int e = t * 256 + tid; yv[t] = e < nrhs * PB ? fb[(size_t)(e >> 7) * ldf + j0 + (e & 127)] : 0.0; }
+#pragma unroll
+  for (int t = 0; t < 3; t++) { const int e = t * 256 + tid; if (e < nrhs * PB) ys[e] = yv[t]; }
+
+  double facc[RF][TRSV_MAXR];
+#pragma unroll
+  for (int t = 0; t < RF; t++)
+#pragma unroll
+    for (int q = 0; q < TRSV_MAXR; q++) facc[t][q] = 0.0;
+  const int sr = tid >> 4, sc = (tid & 15) * 2;             /* store phase: row (+ 16 per pass) and column pair of this thread */
+
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    if (c > 0) {
+#pragma unroll
+      for (int t = 0; t < NRF; t++) {
+        const int rf = KSPLIT ? 0 : g + 2 * t;
+        double4_t acc = cinit[t][c - 1];
+#pragma unroll
+        for (int p = 0; p < c; p++)
+#pragma unroll
+          for (int i = 0; i < LCH; i++) {
+            const int k = 32 * p + 4 * (lk0 + i) + fq;
+            double a = Xp[(16 * rf + fr) * TRX + k];
+            if constexpr (KSPLIT) a += Xp[ROWS * TRX + (16 * rf + fr) * TRX + k];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, lb[c * (c - 1) / 2 + p][i], acc, 0, 0, 0);
+          }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) Yp[plane * ROWS * TRY + (16 * rf + fq + 4 * rg) * TRY + 16 * f + fr] = acc[rg];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NRF; t++) {
+      const int rf = KSPLIT ? 0 : g + 2 * t;
+      double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (i < dch) {
+          const int k = 4 * (dk0 + i) + fq;
+          double a = a0[t][i];
+          if (c > 0) {
+            a = Yp[(16 * rf + fr) * TRY + k];
+            if constexpr (KSPLIT) a += Yp[ROWS * TRY + (16 * rf + fr) * TRY + k];
+          }
+          x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, dv[c][i], x, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) Xp[plane * ROWS * TRX + (16 * rf + fq + 4 * rg) * TRX + 32 * c + 16 * f + fr] = x[rg];
+    }
+    __syncthreads();
+    /* X_c on its way out: 16 RF rows x 32 columns, two columns per thread and pass */
+#pragma unroll
+    for (int t = 0; t < RF; t++) {
+      const int r = sr + 16 * t;
+      double2 xv = *reinterpret_cast<const double2 *>(&Xp[r * TRX + 32 * c + sc]);
+      if constexpr (KSPLIT) {
+        const double2 x1 = *reinterpret_cast<const double2 *>(&Xp[ROWS * TRX + r * TRX + 32 * c + sc]);
+        xv.x += x1.x; xv.y += x1.y;
+      }
+      const size_t grow = row0 + r;
+      if (grow < n) *reinterpret_cast<double2 *>(A + grow * lda + j0 + 32 * c + sc) = xv;
+#pragma unroll
+      for (int q = 0; q < TRSV_MAXR; q++)
+        if (q < nrhs) facc[t][q] = fma(xv.y, ys[q * PB + 32 * c + sc + 1], fma(xv.x, ys[q * PB + 32 * c + sc], facc[t][q]));
+    }
+  }
+  if (nrhs > 0) {
+#pragma unroll
+    for (int t = 0; t < RF; t++) {
+      const size_t grow = row0 + sr + 16 * t;
+#pragma unroll
+      for (int q = 0; q < TRSV_MAXR; q++) {
+        if (q < nrhs) {
+          double v = facc[t][q];
+          v += __shfl_xor(v, 1);
+          v += __shfl_xor(v, 2);
+          v += __shfl_xor(v, 4);
+          v += __shfl_xor(v, 8);
+          if ((tid & 15) == 0 && grow < n) fb[(size_t)q * ldf + grow] -= v;
+        }
+      }
+    }
+  }
+}
+
+template <int RF>
+static int launch_trsm16(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, size_t j0, const double *d_linv, size_t row_start,
+                         double *fb, size_t ldf, int nrhs)
+{
+  constexpr int NP = RF == 1 ? 2 : 1;
+  const size_t lds = (size_t)(NP * 16 * RF * (TRX + TRY) + TRSV_MAXR * PB) * sizeof(double);
+  { int ast = sinterp_func_lds(ctx, (const void *)chol_trsm16_kernel<RF>, (int)lds); if (ast) return ast; }
+  const size_t below = n - row_start;
+  hipLaunchKernelGGL(chol_trsm16_kernel<RF>, dim3((unsigned)((below + 16 * RF - 1) / (16 * RF))), dim3(256), lds, ctx->stream, A, lda, n, j0,
+                     d_linv, row_start, fb, ldf, nrhs);
+  return ST_SUCCESS;
+}
+
+/* tall panels (more than 4 k rows below the block; round 2): 64 rows per workgroup, wave w owns rows 16w..16w+15 for all
+   four 32-column steps, so the steps need no workgroup barrier; B tile, L blocks and Dinv blocks staged in LDS with
+   coalesced 16-byte loads.  144 dependent MFMAs per wave, which only pays when there is a workgroup for every CU. */
+__global__ void __launch_bounds__(256)
+chol_trsm128_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, const double *__restrict__ Dinvg, size_t row_start,
+                    double *__restrict__ fb, size_t ldf, int nrhs)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *Bt = sm;                     /* [64][TR_LD] */
   double *Lb = Bt + 64 * TR_LD;        /* 6 off-diagonal blocks of L: (bi, bj) at bi(bi-1)/2 + bj */
   double *Dvb = Lb + 6 * PBLK;         /* 4 inverted diagonal blocks */
+  double *ys = Dvb + 4 * PBLK;         /* [TRSV_MAXR][PB]: y_p of the folded forward substitution */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const size_t row0 = row_start + (size_t)blockIdx.x * 64;    /* rows [row_start, n): the whole panel below the block, or a slice of it */
   {
     /* one round trip: every global load is issued before the first LDS store */
     double2 vb[16];
-    double vl[24], vd[16];
+    double vl[24], vd[16], yv[3];
     const int r8 = tid >> 5, k = tid & 31;
 #pragma unroll
     for (int t = 0; t < 16; t++) {
@@ -230,10 +457,14 @@ chol_trsm128_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, con
 #pragma unroll
     for (int t = 0; t < 16; t++) vd[t] = Dinvg[(t >> 2) * 1024 + ((t & 3) * 8 + r8) * 32 + k];
 #pragma unroll
+    for (int t = 0; t < 3; t++) { const int e = t * 256 + tid; yv[t] = e < nrhs * PB ? fb[(size_t)(e >> 7) * ldf + j0 + (e & 127)] : 0.0; }
+#pragma unroll
     for (int t = 0; t < 16; t++) {
       const int e = t * 256 + tid, r = e >> 6, k2 = (e & 63) * 2;
       Bt[r * TR_LD + k2] = vb[t].x; Bt[r * TR_LD + k2 + 1] = vb[t].y;
     }
+#pragma unroll
+    for (int t = 0; t < 3; t++) { const int e = t * 256 + tid; if (e < nrhs * PB) ys[e] = yv[t]; }
 #pragma unroll
     for (int t = 0; t < 24; t++) Lb[(t >> 2) * PBLK + ((t & 3) * 8 + r8) * PQ + k] = vl[t];
 #pragma unroll
@@ -282,7 +513,22 @@ chol_trsm128_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, con
         if (grow < n) A[grow * lda + j0 + c * 32 + f * 16 + fr] = acc[f][rg];
       }
   }
+  if (nrhs > 0) {
+    /* folded forward substitution: f[R] -= X_R y_p, X_R is in Bt now (every wave wrote its own rows) */
+    __syncthreads();
+    const int r = tid >> 2, qd = tid & 3;
+    const size_t grow = row0 + r;
+    for (int q = 0; q < nrhs; q++) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 32; k++) v = fma(Bt[r * TR_LD + qd * 32 + k], ys[q * PB + qd * 32 + k], v);
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      if (qd == 0 && grow < n) fb[(size_t)q * ldf + grow] -= v;
+    }
+  }
 }
+
 
 /* upper(i<j) <- lower(j,i)  (matrix/swap_source.c:213, cholesky.c:103) */
 __global__ void __launch_bounds__(256)
@@ -313,23 +559,41 @@ static size_t chol_split(size_t w)
   return w1;
 }
 
+/* fb != NULL: nrhs right-hand sides (fb + q * ldf) ride along -- only ever passed when every leaf of the recursion is a
+   128-wide panel (chol_fold_applicable), see diag128_forward */
 static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, size_t j0, size_t w, int *d_info,
-                      double *d_diag)
+                      double *d_diag, double *fb, size_t ldf, int nrhs)
 {
   int st;
   static const bool no_p128 = getenv("GSL_SINTERP_NO_PANEL128") && getenv("GSL_SINTERP_NO_PANEL128")[0] == '1';
   if (w == PB && !no_p128 && (lda & 1) == 0 && ((((uintptr_t)(A + j0 * lda + j0)) & 15) == 0)) {
     double *d_linv = d_diag + ((n + CB - 1) / CB) * (CB * CB);   /* 4 inverted 32x32 blocks */
-    const size_t lds_diag = (size_t)(14 * PBLK) * sizeof(double), lds_trsm = (size_t)(64 * TR_LD + 10 * PBLK) * sizeof(double);
+    const size_t lds_diag = (size_t)(14 * PBLK + TRSV_MAXR * (PB + CB)) * sizeof(double);
     { int ast = sinterp_func_lds(ctx, (const void *)chol_diag128_kernel, (int)lds_diag); if (ast) return ast; }
-    { int ast = sinterp_func_lds(ctx, (const void *)chol_trsm128_kernel, (int)lds_trsm); if (ast) return ast; }
-    hipLaunchKernelGGL(chol_diag128_kernel, dim3(1), dim3(256), lds_diag, ctx->stream, A, lda, j0, d_info, d_diag, d_linv);
+    hipLaunchKernelGGL(chol_diag128_kernel, dim3(1), dim3(256), lds_diag, ctx->stream, A, lda, j0, d_info, d_diag, d_linv, fb, ldf, nrhs);
     const size_t below = n - j0 - w;
-    if (below)
-      hipLaunchKernelGGL(chol_trsm128_kernel, dim3((unsigned)((below + 63) / 64)), dim3(256), lds_trsm, ctx->stream, A, lda, n, j0,
-                         (const double *)d_linv, j0 + PB);
+    if (below) {
+      /* 16 rows per workgroup while that is at most about one workgroup per CU, 64-row strips above
+         (developer override: GSL_SINTERP_TRSM_RF = 1, 2, 4 forces the 16 RF-row kernel, 64 the strip kernel) */
+      static const int force_rf = getenv("GSL_SINTERP_TRSM_RF") ? atoi(getenv("GSL_SINTERP_TRSM_RF")) : 0;
+      int ast = 0;
+      if (force_rf == 1 || (!force_rf && below <= 4096)) ast = launch_trsm16<1>(ctx, A, lda, n, j0, d_linv, j0 + PB, fb, ldf, nrhs);
+      else if (force_rf == 2) ast = launch_trsm16<2>(ctx, A, lda, n, j0, d_linv, j0 + PB, fb, ldf, nrhs);
+      else if (force_rf == 4) ast = launch_trsm16<4>(ctx, A, lda, n, j0, d_linv, j0 + PB, fb, ldf, nrhs);
+      else {
+        const size_t lds_trsm = (size_t)(64 * TR_LD + 10 * PBLK + TRSV_MAXR * PB) * sizeof(double);
+        ast = sinterp_func_lds(ctx, (const void *)chol_trsm128_kernel, (int)lds_trsm);
+        if (!ast)
+          hipLaunchKernelGGL(chol_trsm128_kernel, dim3((unsigned)((below + 63) / 64)), dim3(256), lds_trsm, ctx->stream, A, lda, n, j0,
+                             (const double *)d_linv, j0 + PB, fb, ldf, nrhs);
+      }
+      if (ast) return ast;
+    }
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
+  }
+  if (w <= PB) {
+    if (fb) return sinterp_fail(ctx, ST_EFAILED, "cholesky: folded forward substitution on a panel that is not 128 wide", hipSuccess, __FILE__, __LINE__);
   }
   if (w <= CB) {
     const size_t below = n - j0 - w;
@@ -339,12 +603,20 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
     return ST_SUCCESS;
   }
   const size_t w1 = chol_split(w);
-  st = chol_panel(ctx, A, lda, n, j0, w1, d_info, d_diag);
+  st = chol_panel(ctx, A, lda, n, j0, w1, d_info, d_diag, fb, ldf, nrhs);
   if (st) return st;
   const size_t r0 = j0 + w1, w2 = w - w1;
   st = sinterp_gemm_minus(ctx, n - r0, w2, w1, A + r0 * lda + j0, lda, A + r0 * lda + j0, lda, 0, A + r0 * lda + r0, lda, 1);
   if (st) return st;
-  return chol_panel(ctx, A, lda, n, r0, w2, d_info, d_diag);
+  return chol_panel(ctx, A, lda, n, r0, w2, d_info, d_diag, fb, ldf, nrhs);
+}
+
+/* every leaf of the recursion is a 128-wide panel: the forward substitution can ride along */
+static bool chol_fold_applicable(size_t n, const double *d_a, size_t lda, int nrhs)
+{
+  static const bool no_p128 = getenv("GSL_SINTERP_NO_PANEL128") && getenv("GSL_SINTERP_NO_PANEL128")[0] == '1';
+  static const bool no_fold = getenv("GSL_SINTERP_NO_FOLD") && getenv("GSL_SINTERP_NO_FOLD")[0] == '1';
+  return !no_p128 && !no_fold && nrhs >= 1 && nrhs <= TRSV_MAXR && n >= PB && n % PB == 0 && (lda & 1) == 0 && ((((uintptr_t)d_a) & 15) == 0);
 }
 
 
@@ -352,8 +624,11 @@ __global__ void chol_zero_info_kernel(int *info) { *info = 0; }
 
 /* symmetric_input: both triangles of d_a hold the matrix (the RBF fill writes it that way), so the
    copy that preserves the original in the strict upper triangle (cholesky.c:103) is already there */
-static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, bool symmetric_input)
+/* fb / ldf / nrhs: optional right-hand sides for the folded forward substitution; *h_folded = 1 when fb holds L^-1 f on return */
+static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, bool symmetric_input,
+                                 double *fb, size_t ldf, int nrhs, int *h_folded)
 {
+  if (h_folded) *h_folded = 0;
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
   EXCLUSIVE_SECTION(ctx);                         /* launches kernels that spin on sibling workgroups */
@@ -371,8 +646,11 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
   if (st) return st;
   st = sinterp_streamk_prepare(ctx);
   if (st) return st;
+  const bool fold = fb != NULL && chol_fold_applicable(n, d_a, lda, nrhs) && ldf >= n;
+  if (!fold) { fb = NULL; nrhs = 0; }
   int replayed = 0;
-  const void *gkey = symmetric_input ? (const void *)(uintptr_t)1 : NULL;
+  /* graph key: the right-hand-side buffer (16-byte aligned or not, its low bits are free below bit 3), their count and stride */
+  const void *gkey = (const void *)(((uintptr_t)fb & ~(uintptr_t)7) ^ (uintptr_t)(symmetric_input ? 1 : 0) ^ ((uintptr_t)nrhs << 1) ^ ((uintptr_t)ldf << 44));
   st = sinterp_graph_try_launch(ctx, 0, n, lda, d_a, gkey, &replayed);
   if (st) return st;
   if (!replayed) {
@@ -385,7 +663,7 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
     hipError_t me = hipSuccess;
     const unsigned nt = (unsigned)((n + 31) / 32);
     if (!symmetric_input) hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
-    st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag);
+    st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag, fb, ldf, nrhs);
     hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
                        (const double *)d_diag);
     int st2 = sinterp_capture_end(ctx, saved, 0, n, lda, d_a, gkey);
@@ -403,17 +681,36 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
     snprintf(ctx->err, sizeof ctx->err, "cholesky_decomp1: matrix is not positive definite (pivot %d of %zu <= 0)", info, n);
     return ST_EDOM;
   }
+  if (h_folded) *h_folded = fold ? 1 : 0;
   return ST_SUCCESS;
 }
 
 extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info)
 {
-  return cholesky_decomp1_impl(ctx, n, d_a, lda, h_info, false);
+  return cholesky_decomp1_impl(ctx, n, d_a, lda, h_info, false, NULL, 0, 0, NULL);
 }
 
 int sinterp_cholesky_decomp1_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info)
 {
-  return cholesky_decomp1_impl(ctx, n, d_a, lda, h_info, true);
+  return cholesky_decomp1_impl(ctx, n, d_a, lda, h_info, true, NULL, 0, 0, NULL);
+}
+
+/* factor (symmetric input) and solve: d_x (nrhs vectors, d_x + q * ldx) <- (L L^T)^-1 d_x.  When every panel is 128 wide the
+   forward substitution rides along with the factorisation and only the backward sweep remains (cholesky.c:178-181 does
+   L c = b, then L^T x = c). */
+int sinterp_cholesky_factor_solve_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, double *d_x, size_t ldx,
+                                      int nrhs)
+{
+  int folded = 0;
+  int st = cholesky_decomp1_impl(ctx, n, d_a, lda, h_info, true, d_x, ldx, nrhs, &folded);
+  if (st) return st;
+  if (!folded) return sinterp_cholesky_svx_multi(ctx, n, d_a, lda, d_x, ldx, nrhs);
+  EXCLUSIVE_SECTION(ctx);
+  void *d_tmp = NULL;
+  st = sinterp_workspace(ctx, (size_t)nrhs * ldx * sizeof(double), &d_tmp);
+  if (st) return st;
+  HIP_OK(ctx, hipMemcpyAsync(d_tmp, d_x, (size_t)nrhs * ldx * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return sinterp_trsv_multi(ctx, n, d_a, lda, (double *)d_tmp, d_x, ldx, nrhs, 1, 0);   /* L^T x = c */
 }
 
 /* ------------------------------------------------------------------------ */
@@ -424,7 +721,6 @@ int sinterp_cholesky_decomp1_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
      mode 1: Lower, Trans,  backward   (source_trsv_r.h:106-129)  cols i < J:  b_i -= sum_j T[j][i] x_j
      mode 2: Upper, NoTrans, backward  (source_trsv_r.h:33-55)    rows i < J:  b_i -= sum_j T[i][j] x_j   */
 #define TS 64
-#define TRSV_MAXR 5   /* right-hand sides solved together (f + the d+1 polynomial columns) */
 
 /* right-hand side r lives at b + r*ldb (solved blocks at xout + r*ldb) */
 __global__ void __launch_bounds__(256)

@@ -50,85 +50,96 @@ __device__ __forceinline__ void frag_store(double *Cb, int fi, int fj, int lane,
 
 
 /* potrf32 on one wave: lane = row, the row's 32 entries in registers, left-looking; compile-time
-   recursion over the columns (straight-line code, no branch per column: a failing pivot is recorded
-   and reported once at the end).
-   Column J+1 of row i is  a_i[J+1] - sum_{k<=J} L[i][k] L[J+1][k].  Row J+1 of L has to reach every
-   lane: a readlane pair per entry (the obvious way) makes the kernel issue bound.  Instead every
-   finished column is stored to the LDS image of the block (one ds_write_b64 per column), and row
-   J+1's entries k < J -- final before column J starts -- come back as uniform-address ds_read_b128
-   (two entries per instruction), issued before column J's rsq chain and consumed in its latency
-   shadow (a wave issues in order: the FMAs are interleaved by hand between the ~8 dependent chain
-   ops, sched_barrier pins the order).  Only the k = J term needs a readlane. */
-template <int J, int SLOT>
-__device__ __forceinline__ void potrf32_fill(const double (&a)[CB], const double (&rp)[CB], double rlast, double (&p)[2])
-{
-  /* partial dot product of column J+1: terms k < J-1 use row entries fetched one column ago (rp), the
-     term k = J-1 the entry fetched at the start of this column (rlast), consumed last; two accumulators
-     (the wave issues in order and an fp64 FMA occupies the VALU for 4 cycles: two chains already hide its
-     latency, and every extra accumulator is one more add on the dependent path into the next column) */
-  if constexpr (J + 1 < CB && SLOT >= 2 && SLOT <= 6 && J >= 2) {
-#pragma unroll
-    for (int k = ((SLOT - 2) * (J - 1)) / 5; k < ((SLOT - 1) * (J - 1)) / 5; k++) p[k & 1] = fma(-a[k], rp[k], p[k & 1]);
-  }
-  if constexpr (J + 1 < CB && SLOT == 7 && J >= 1) p[(J - 1) & 1] = fma(-a[J - 1], rlast, p[(J - 1) & 1]);
-  __builtin_amdgcn_sched_barrier(0);
-}
+   recursion over the columns (straight-line code, no branch per column: a failing pivot shows up as a
+   NaN diagonal and is reported once at the end).
 
-/* rp: entries k < J-1 of row J+1 of L, fetched from the LDS image during column J-1 */
+   Round 4: the pivot chain runs on UNIFORM values.  Write V_J[i] = A[i][J] - sum_{k<J} L[i][k] L[J][k]
+   (lane i), d_J = V_J[J], inv_J = 1/sqrt(d_J), L[i][J] = V_J[i] inv_J.  The round-2 kernel went
+   lane values -> readlane -> d_J -> rsq chain -> lane values -> readlane -> ... : two cross-lane hops
+   (~26 cycles each) sat on the dependent path of every column.  Here every lane carries the chain
+   redundantly:
+       uL      = e inv_{J-1}                e = V_{J-1}[J]        (= L[J][J-1])
+       d_J     = q - uL^2                   q = (A[J][J] - sum_{k<=J-2} L[J][k]^2), lane J's partial dot product
+       inv_J   = rsq chain of d_J
+   e and q are readlanes of values that are final one column EARLIER (V_{J-1} needs inv_{J-2} only, the partial dot
+   product needs the columns <= J-2), so their latency is off the chain; what remains on it is 2 + 1 + 4 dependent
+   fp64 ops (~50 cycles).  The column time is then the wave's in-order issue: ~20 instructions + the J-term dot
+   product of the next column (terms k <= J-2 against row J+1 of L from the LDS image -- uniform ds_read_b128,
+   fetched a column ahead --, the term k = J-1 against e2 inv_{J-1}, e2 = V_{J-1}[J+1], a third readlane).
+   d_J formed this way is bit-identical to V_J[J] (same operands, same fma).  */
+/* Order pins.  The column body below is written in the order the wave should issue it (it issues in order); the
+   compiler's schedulers otherwise sink the LDS prefetch down to its use a column later (an LDS round trip on the
+   dependent path of every column) and the pivot readlane behind the chain tail.  An empty volatile asm that takes values
+   as read-write operands is a join point: every producer of those values comes before it, every consumer after, and
+   the "memory" clobber keeps the LDS accesses on their side.  No instruction is emitted. */
+#define PIN_V2(x, y)       asm volatile("" : "+v"(x), "+v"(y) : : "memory")
+#define PIN_V4(x, y, z, w) asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : : "memory")
+#define PIN_SSV(x, y, z)   asm volatile("" : "+s"(x), "+s"(y), "+v"(z) : : "memory")
+#define PIN_SV(x, y)       asm volatile("" : "+s"(x), "+v"(y) : : "memory")
+
 template <int J>
-__device__ __forceinline__ void potrf32_cols(double (&a)[CB], int lane, double cur, int &badcol, const double *D, double *colp,
-                                             int cstride, const double (&rp)[CB])
+__device__ __forceinline__ void potrf32_step(double (&a)[CB], double vprev, double cur, double inv_prev, double e, double e2, double q,
+                                             const double *D, double *colp, int cstride, const double (&rp)[CB])
 {
   if constexpr (J < CB) {
     TSTAMP(32 + J);
-    double v = cur;
-    if constexpr (J > 0) v = fma(-a[J - 1], lane_bcast(a[J - 1], J), v);
-    double d = lane_bcast(v, J);
-    /* LDS reads issued now: the one entry of row J+1 that column J-1 just produced (used in the last
-       fill slot of this column), and row J+2's entries k < J for the NEXT column -- a full column
-       (~200 cycles) ahead of their use, so the ~70-cycle LDS latency never stalls the in-order wave */
-    double rlast = 0.0;
-    if constexpr (J >= 1 && J + 1 < CB) rlast = D[(J + 1) * PQ + (J - 1)];
+    /* ---- head of the chain: d_J and the rsq seed */
+    double v, d, uL2 = 0.0, acol = 0.0;
+    if constexpr (J == 0) {
+      v = cur;
+      d = lane_bcast(v, 0);
+    } else {
+      const double uL = e * inv_prev;                   /* L[J][J-1], uniform */
+      d = fma(-uL, uL, q);                              /* uniform; = V_J[J] bit for bit */
+      acol = vprev * inv_prev;                          /* column J-1 of L (lanes >= 32: of L^-1) */
+      v = fma(-acol, uL, cur);                          /* V_J */
+      uL2 = e2 * inv_prev;                              /* L[J+1][J-1], uniform */
+    }
+    double y0 = __builtin_amdgcn_rsq(d);
+    PIN_V4(y0, v, uL2, acol);
+    /* ---- in the shadow of the rsq: column J-1 to the LDS image, the prefetch for the NEXT column's dot product (row
+       J+2's entries k < J: columns <= J-1 are in the image, the store precedes these reads in the wave's in-order
+       LDS queue), and the two broadcasts of V_J the next column starts from */
+    if constexpr (J > 0) { a[J - 1] = acol; colp[(J - 1) * cstride] = acol; }
     double rn[CB];
     if constexpr (J + 2 < CB) {
 #pragma unroll
       for (int k = 0; k < J; k += 2) {
-        const double2 t = *reinterpret_cast<const double2 *>(D + (J + 2) * PQ + k);
-        rn[k] = t.x;
-        if (k + 1 < CB) rn[k + 1] = t.y;
+        const double2 t2 = *reinterpret_cast<const double2 *>(D + (J + 2) * PQ + k);
+        rn[k] = t2.x;
+        if (k + 1 < CB) rn[k + 1] = t2.y;
       }
     }
-    /* cholesky.c:120-123: a pivot <= 0 is RECORDED (first failing column wins), off the dependent chain: the
-       rsq below then yields inf / NaN, which flows through the rest of the block; the caller reports GSL_EDOM
-       and the content of a failed factorisation is unspecified (as in the reference, which stops mid-way).
-       (the test itself is issued after the rsq, below) */
-    /* 1/sqrt(d) = y0 (1 - r)^(-1/2), r = 1 - d y0^2 with the v_rsq_f64 seed y0 (|r| <~ 2^-21):
-       y0 (1 + r/2 + 3 r^2/8) is exact to r^3 ~ 1e-19 -- four dependent ops after the seed instead
-       of the seven of a Newton step plus correction.  The diagonal entry sqrt(d) = d / sqrt(d) is the
-       SAME product v * inv every row forms (lane J holds v = d), so no lane needs a special case; it
-       ends within ~2 ulp of cholesky.c:125-126's sqrt (a separate residual correction for that one
-       entry cost 9 instructions per column on the wave's in-order issue path). */
-    double p[2] = {0.0, 0.0};
-    if constexpr (J + 1 < CB) p[0] = a[J + 1];
-    const double y0 = __builtin_amdgcn_rsq(d);
-    __builtin_amdgcn_sched_barrier(0);
-    const bool ok = d > 0.0;                            /* in the latency shadow of the rsq */
-    badcol = (!ok && badcol == 0) ? J + 1 : badcol;
-    potrf32_fill<J, 0>(a, rp, rlast, p);
+    double en = 0.0, e2n = 0.0, qn = 0.0, curn = 0.0;
+    if constexpr (J + 1 < CB) en = lane_bcast(v, J + 1);
+    if constexpr (J + 2 < CB) e2n = lane_bcast(v, J + 2);
+    /* ---- partial dot product of column J+1: terms k <= J-1 (two accumulators), then lane J+1's value of it */
+    if constexpr (J + 1 < CB) {
+      double p0 = a[J + 1], p1 = 0.0;
+      if constexpr (J >= 1) p1 = -acol * uL2;           /* the term k = J-1 opens the second accumulator */
+      PIN_SSV(en, e2n, p0);
+#pragma unroll
+      for (int k = 0; k + 1 < J; k++) {
+        if (k & 1) p1 = fma(-a[k], rp[k], p1);
+        else p0 = fma(-a[k], rp[k], p0);
+      }
+      curn = (J >= 1) ? p0 + p1 : p0;
+      qn = lane_bcast(curn, J + 1);
+      PIN_SV(qn, y0);
+    }
+    /* ---- tail of the chain (q's readlane latency hides behind it).
+       1/sqrt(d) = y0 (1 - r)^(-1/2), r = 1 - d y0^2 with the v_rsq_f64 seed y0 (|r| <~ 2^-21):
+       y0 (1 + r/2 + 3 r^2/8) is exact to r^3 ~ 1e-19 -- four dependent ops after the seed.  The diagonal entry
+       sqrt(d) = d / sqrt(d) is the SAME product v * inv every row forms (lane J holds v = d); it ends within
+       ~2 ulp of cholesky.c:125-126's sqrt. */
     const double t = d * y0;
-    potrf32_fill<J, 1>(a, rp, rlast, p);
     const double rr = fma(-t, y0, 1.0);
-    potrf32_fill<J, 2>(a, rp, rlast, p);
     const double s1 = fma(0.375, rr, 0.5), u = y0 * rr;
-    potrf32_fill<J, 3>(a, rp, rlast, p);
     const double inv = fma(u, s1, y0);
-    potrf32_fill<J, 4>(a, rp, rlast, p);
-    a[J] = v * inv;
-    potrf32_fill<J, 5>(a, rp, rlast, p);
-    colp[J * cstride] = a[J];                           /* column J of L (row reads of later columns) / of L^-1 */
-    potrf32_fill<J, 6>(a, rp, rlast, p);
-    potrf32_fill<J, 7>(a, rp, rlast, p);
-    potrf32_cols<J + 1>(a, lane, p[0] + p[1], badcol, D, colp, cstride, rn);
+    potrf32_step<J + 1>(a, v, curn, inv, en, e2n, qn, D, colp, cstride, rn);
+  } else {
+    a[CB - 1] = vprev * inv_prev;
+    colp[(CB - 1) * cstride] = a[CB - 1];
   }
 }
 
@@ -169,12 +180,17 @@ __device__ __forceinline__ void potrf128_lds(double *S, double *Dv, int tid, int
     }
     double *colp = is_row ? D + lane * PQ : Dv + jb * PBLK + c;   /* entry J of this lane's vector: colp[J * cstride] */
     const int cstride = is_row ? 1 : PQ;
-    int badcol = 0;
     double r0[CB];                                      /* nothing prefetched before column 0 */
-    potrf32_cols<0>(a, lane, a[0], badcol, D, colp, cstride, r0);
+    potrf32_step<0>(a, 0.0, a[0], 0.0, 0.0, 0.0, 0.0, D, colp, cstride, r0);
     /* every column was written to D as it was produced (colp); the strict upper triangle of a diagonal
-       block is never read afterwards (TRSM uses Dv, the write-back masks k <= r) */
-    if (badcol && lane == 0) atomicCAS(info, 0, (int)(j0 + jb * 32 + badcol));
+       block is never read afterwards (TRSM uses Dv, the write-back masks k <= r).
+       cholesky.c:120-123: a pivot d <= 0 makes the rsq chain produce NaN (d < 0: rsq = NaN; d = 0: 0 * inf), which
+       flows into every later column, so the FIRST row whose diagonal entry is not a positive number is the failing
+       column; the caller reports GSL_EDOM and the content of a failed factorisation is unspecified (as in the
+       reference, which stops mid-way).  One LDS read + one ballot per block instead of a test per column. */
+    const double dg = D[(lane & (CB - 1)) * PQ + (lane & (CB - 1))];
+    const unsigned long long badm = __ballot(is_row && !(dg > 0.0));
+    if (badm && lane == 0) atomicCAS(info, 0, (int)(j0 + jb * 32 + __ffsll((long long)badm)));
   };
   auto update_frag = [&](int jb, int bi, int bj, int f) {
     double *Cb = S + pblk(bi, bj);

@@ -149,6 +149,9 @@ int sinterp_cholesky_svx_multi(gsl_sinterp_hip_ctx *ctx, size_t n, const double 
                                int nrhs);
 /* gsl_sinterp_hip_cholesky_decomp1 for an input that is stored symmetrically (both triangles valid) */
 int sinterp_cholesky_decomp1_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info);
+/* the same followed by the solve of nrhs right-hand sides in place (forward substitution folded into the factorisation when every panel is 128 wide) */
+int sinterp_cholesky_factor_solve_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, double *d_x, size_t ldx,
+                                      int nrhs);
 /* second grow-only buffer for vectors that must outlive factorisation workspaces */
 int sinterp_aux(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 int sinterp_invbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);

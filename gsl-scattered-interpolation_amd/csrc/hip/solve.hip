@@ -167,10 +167,11 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
   int info = 0;
 
   if (spd) {
-    st = sinterp_cholesky_decomp1_sym(ctx, n, d_phi, lda, &info);   /* the fill (and the shift) write both triangles */
+    /* the fill (and the shift) write both triangles; the forward substitution rides along with the factorisation */
+    st = sinterp_cholesky_factor_solve_sym(ctx, n, d_phi, lda, &info, d_w, n, 1);
     if (st) return st;
     if (h_route) *h_route = 1;
-    return gsl_sinterp_hip_cholesky_svx(ctx, n, d_phi, lda, d_w);
+    return ST_SUCCESS;
   }
 
   /* ---- conditionally positive definite kernel: shifted SPD system + Woodbury */
@@ -196,10 +197,8 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
     hipLaunchKernelGGL(poly_shift_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, d_phi, lda, n,
                        (const double *)Pk, k, cmul, (const unsigned long long *)d_norm);
     LAUNCH_CHECK(ctx);
-    st = sinterp_cholesky_decomp1_sym(ctx, n, d_phi, lda, &info);   /* the fill (and the shift) write both triangles */
-    if (st == ST_EDOM) continue;                  /* not SPD with this shift: larger shift, then LU */
-    if (st) return st;
-    st = sinterp_cholesky_svx_multi(ctx, n, d_phi, lda, Y, n, k + 1);
+    st = sinterp_cholesky_factor_solve_sym(ctx, n, d_phi, lda, &info, Y, n, k + 1);   /* the fill (and the shift) write both triangles */
+    if (st == ST_EDOM) continue;                  /* not SPD with this shift: larger shift (Y is rebuilt), then LU */
     if (st) return st;
     hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(k * (k + 1))), dim3(256), 0, ctx->stream, (const double *)Pk, (const double *)Y,
                        n, k, G);
@@ -367,10 +366,8 @@ extern "C" int gsl_sinterp_hip_krige_solve(gsl_sinterp_hip_ctx *ctx, int kind, d
     LAUNCH_CHECK(ctx);
     if (attempt == 0) {
       int info = 0;
-      st = sinterp_cholesky_decomp1_sym(ctx, n, d_phi, lda, &info);
-      if (st == ST_EDOM) continue;                                                      /* only semi-definite: pivoted LDL^T */
-      if (st) return st;
-      st = sinterp_cholesky_svx_multi(ctx, n, d_phi, lda, Y, n, 2);
+      st = sinterp_cholesky_factor_solve_sym(ctx, n, d_phi, lda, &info, Y, n, 2);
+      if (st == ST_EDOM) continue;                                                      /* only semi-definite: pivoted LDL^T (Y is rebuilt) */
       if (st) return st;
       break;
     }
