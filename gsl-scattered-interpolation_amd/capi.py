@@ -216,6 +216,9 @@ SIGNATURES = {
     "gsl_sinterp_set_solver": (_i, [C.POINTER(gsl_sinterp), _i]),
     "gsl_sinterp_set_nugget": (_i, [C.POINTER(gsl_sinterp), _d]),
     "gsl_sinterp_mean": (_i, [C.POINTER(gsl_sinterp), _pd]),
+    "gsl_sinterp_poly": (_i, [C.POINTER(gsl_sinterp), _pv]),
+    "gsl_sinterp_hip_rbf_solve_affine": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _pd, _pi]),
+    "gsl_sinterp_hip_rbf_eval_affine": (_i, [_vp, _i, _d, _pd, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp, C.c_uint64]),
     "gsl_sinterp_hip_krige_solve": (_i, [_vp, _i, _d, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _pd, _pi]),
     "gsl_sinterp_hip_krige_eval": (_i, [_vp, _i, _d, _d, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp, C.c_uint64]),
     "gsl_sinterp_set_rcond": (_i, [C.POINTER(gsl_sinterp), _i]),
@@ -246,7 +249,7 @@ SIGNATURES = {
     "gsl_rng_get": (C.c_ulong, [_vp]),
     "gsl_rng_uniform_int": (C.c_ulong, [_vp, C.c_ulong]),
 }
-DATA_SYMBOLS = ["gsl_sinterp_kriging", "gsl_sinterp_rbf_gaussian", "gsl_sinterp_rbf_tps", "gsl_sinterp_rbf_wendland", "gsl_sinterp_linear_simplex",
+DATA_SYMBOLS = ["gsl_sinterp_kriging", "gsl_sinterp_rbf_gaussian", "gsl_sinterp_rbf_tps", "gsl_sinterp_rbf_tps_affine", "gsl_sinterp_rbf_wendland", "gsl_sinterp_linear_simplex",
                 "gsl_rng_mt19937", "gsl_rng_default"]
 
 
@@ -763,7 +766,8 @@ class DeviceMesh:
 
 # ------------------------------------------------------------------ facade
 class Sinterp:
-    TYPES = {"gaussian": "gsl_sinterp_rbf_gaussian", "tps": "gsl_sinterp_rbf_tps", "wendland": "gsl_sinterp_rbf_wendland",
+    TYPES = {"gaussian": "gsl_sinterp_rbf_gaussian", "tps": "gsl_sinterp_rbf_tps", "tps_affine": "gsl_sinterp_rbf_tps_affine",
+             "wendland": "gsl_sinterp_rbf_wendland",
              "linear_simplex": "gsl_sinterp_linear_simplex", "kriging": "gsl_sinterp_kriging"}
 
     def __init__(self, kind, dim, size, device=0):
@@ -783,6 +787,11 @@ class Sinterp:
         v = C.c_double(0)
         st = lib().gsl_sinterp_mean(self._p, C.byref(v))
         return st, v.value
+
+    def poly(self):
+        c = np.zeros(self._p.contents.dim + 1, dtype=np.float64)
+        st = lib().gsl_sinterp_poly(self._p, C.byref(as_vector(c)))
+        return st, c
 
     def set_solver(self, solver):
         return lib().gsl_sinterp_set_solver(self._p, solver)

@@ -625,8 +625,25 @@ __global__ void chol_zero_info_kernel(int *info) { *info = 0; }
 /* symmetric_input: both triangles of d_a hold the matrix (the RBF fill writes it that way), so the
    copy that preserves the original in the strict upper triangle (cholesky.c:103) is already there */
 /* fb / ldf / nrhs: optional right-hand sides for the folded forward substitution; *h_folded = 1 when fb holds L^-1 f on return */
+/* defer_info: return right after the launches; the caller reads the pivot status later with chol_read_info (one host
+   round trip for the factorisation AND whatever the caller enqueues behind it) */
+static int chol_read_info(gsl_sinterp_hip_ctx *ctx, size_t n, int *h_info)
+{
+  int *d_info = (int *)ctx->d_scratch + 8;
+  int info = 0;
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(&info, d_info, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_info) *h_info = info;
+  if (info) {
+    snprintf(ctx->err, sizeof ctx->err, "cholesky_decomp1: matrix is not positive definite (pivot %d of %zu <= 0)", info, n);
+    return ST_EDOM;
+  }
+  return ST_SUCCESS;
+}
+
 static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, bool symmetric_input,
-                                 double *fb, size_t ldf, int nrhs, int *h_folded)
+                                 double *fb, size_t ldf, int nrhs, int *h_folded, bool defer_info = false)
 {
   if (h_folded) *h_folded = 0;
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
@@ -672,17 +689,11 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
     if (st2) return st2;
     LAUNCH_CHECK(ctx);
   }
-  int info = 0;
-  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_OK(ctx, hipMemcpy(&info, d_info, sizeof(int), hipMemcpyDeviceToHost));
-  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
-  if (h_info) *h_info = info;
-  if (info) {
-    snprintf(ctx->err, sizeof ctx->err, "cholesky_decomp1: matrix is not positive definite (pivot %d of %zu <= 0)", info, n);
-    return ST_EDOM;
-  }
   if (h_folded) *h_folded = fold ? 1 : 0;
-  return ST_SUCCESS;
+  if (defer_info) return ST_SUCCESS;
+  st = chol_read_info(ctx, n, h_info);
+  if (st && h_folded) *h_folded = 0;
+  return st;
 }
 
 extern "C" int gsl_sinterp_hip_cholesky_decomp1(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info)
@@ -701,16 +712,17 @@ int sinterp_cholesky_decomp1_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
 int sinterp_cholesky_factor_solve_sym(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a, size_t lda, int *h_info, double *d_x, size_t ldx,
                                       int nrhs)
 {
-  int folded = 0;
-  int st = cholesky_decomp1_impl(ctx, n, d_a, lda, h_info, true, d_x, ldx, nrhs, &folded);
-  if (st) return st;
-  if (!folded) return sinterp_cholesky_svx_multi(ctx, n, d_a, lda, d_x, ldx, nrhs);
   EXCLUSIVE_SECTION(ctx);
-  void *d_tmp = NULL;
-  st = sinterp_workspace(ctx, (size_t)nrhs * ldx * sizeof(double), &d_tmp);
+  int folded = 0;
+  /* the sweeps are enqueued behind the factorisation without waiting for its pivot status: a failed factorisation
+     leaves NaN in L, the sweeps carry them through (their hand-offs wait on epochs, not on values), and the one
+     host round trip at the end reports GSL_EDOM */
+  int st = cholesky_decomp1_impl(ctx, n, d_a, lda, h_info, true, d_x, ldx, nrhs, &folded, true);
   if (st) return st;
-  HIP_OK(ctx, hipMemcpyAsync(d_tmp, d_x, (size_t)nrhs * ldx * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  return sinterp_trsv_multi(ctx, n, d_a, lda, (double *)d_tmp, d_x, ldx, nrhs, 1, 0);   /* L^T x = c */
+  if (!folded) st = sinterp_cholesky_svx_multi(ctx, n, d_a, lda, d_x, ldx, nrhs);
+  else st = sinterp_trsv_multi(ctx, n, d_a, lda, d_x, d_x, ldx, nrhs, 1, 0);                /* L^T x = c, in place */
+  if (st) return st;
+  return chol_read_info(ctx, n, h_info);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1192,6 +1204,15 @@ static int trsv_launches(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
 
 /* inv_ready: the inverted diagonal blocks of this very triangle are still in the context's buffer
    (the backward sweep of a Cholesky solve right after its forward sweep) */
+__global__ void __launch_bounds__(256)
+vec_copy_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t count)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) dst[i] = src[i];
+}
+
+/* b == xout (in place): the right-hand sides are copied to the context's second grow-only buffer by a kernel inside the
+   same captured graph, and the sweep reads the copy */
 static int trsv_multi_ex(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, size_t ldt, double *b, double *xout, size_t ldb,
                          int nrhs, int mode, int unit, int inv_ready)
 {
@@ -1205,7 +1226,12 @@ static int trsv_multi_ex(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
   int st = sinterp_graph_try_launch(ctx, slot, n, key_lda, T, p1, &replayed);
   if (st || replayed) return st;
   void *d_inv = NULL;
-  st = sinterp_invbuf(ctx, ((n + TS - 1) / TS) * TS * TS * sizeof(double), &d_inv);
+  const size_t inv_bytes = ((n + TS - 1) / TS) * TS * TS * sizeof(double);
+  const bool in_place = b == xout;
+  if (in_place && inv_ready) return sinterp_fail(ctx, ST_EINVAL, "trsv: in-place sweep cannot reuse inverted blocks", hipSuccess, __FILE__, __LINE__);
+  /* the copy of an in-place sweep's right-hand sides lives behind the inverted blocks (a buffer whose growth already
+     invalidates the cached sweep graphs) */
+  st = sinterp_invbuf(ctx, inv_bytes + (in_place ? (size_t)nrhs * ldb * sizeof(double) : 0), &d_inv);
   if (st) return st;
   {
     /* epoch + per-block flags of the dataflow sweep: grown (and zeroed) outside capture only */
@@ -1228,10 +1254,15 @@ static int trsv_multi_ex(gsl_sinterp_hip_ctx *ctx, size_t n, const double *T, si
   }
   st = sinterp_streamk_prepare(ctx);                   /* CU count (the dataflow sweep needs co-resident workgroups) */
   if (st) return st;
+  double *b_src = in_place ? (double *)((char *)d_inv + inv_bytes) : b;
   hipStream_t saved;
   st = sinterp_capture_begin(ctx, &saved);
   if (st) return st;
-  st = trsv_launches(ctx, n, T, ldt, b, xout, ldb, nrhs, mode, unit, (double *)d_inv, inv_ready);
+  if (in_place) {
+    const size_t cnt = (size_t)(nrhs - 1) * ldb + n;
+    hipLaunchKernelGGL(vec_copy_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)b, b_src, cnt);
+  }
+  st = trsv_launches(ctx, n, T, ldt, b_src, xout, ldb, nrhs, mode, unit, (double *)d_inv, inv_ready);
   int st2 = sinterp_capture_end(ctx, saved, slot, n, key_lda, T, p1);
   return st ? st : st2;
 }

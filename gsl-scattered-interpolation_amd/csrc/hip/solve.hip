@@ -27,7 +27,7 @@
    (vector 0 = f, vectors 1..k = P columns), Pk keeps a copy of P. */
 __global__ void __launch_bounds__(1024)
 poly_block_kernel(const double *__restrict__ x, size_t n, int dim, size_t xtda, const double *__restrict__ f,
-                  double *__restrict__ Y, double *__restrict__ Pk)
+                  double *__restrict__ Y, double *__restrict__ Pk, double *__restrict__ stats)
 {
   __shared__ double s_red[2 * 3][16];
   __shared__ double s_mean[3], s_inv[3];
@@ -49,6 +49,7 @@ poly_block_kernel(const double *__restrict__ x, size_t n, int dim, size_t xtda, 
     if (!(var > 0)) var = 1.0;
     s_mean[tid] = mean;
     s_inv[tid] = 1.0 / sqrt(var);
+    if (stats) { stats[tid] = mean; stats[3 + tid] = s_inv[tid]; }     /* the affine tail is reported in raw coordinates */
   }
   __syncthreads();
   for (size_t i = tid; i < n; i += 1024) {
@@ -140,7 +141,7 @@ static int host_solve(int k, double *S, double *g)
 }
 
 static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim, size_t xtda,
-                          double *d_phi, size_t lda, double *d_w, int *h_route, bool keep_upper);
+                          double *d_phi, size_t lda, double *d_w, int *h_route, bool keep_upper, double *h_poly = NULL);
 
 extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n,
                                          int dim, size_t xtda, double *d_phi, size_t lda, double *d_w, int *h_route)
@@ -149,8 +150,18 @@ extern "C" int gsl_sinterp_hip_rbf_solve(gsl_sinterp_hip_ctx *ctx, int kind, dou
   return rbf_solve_impl(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, h_route, false);
 }
 
+/* h_poly != NULL (thin-plate spline only): the affine-augmented system
+       [Phi P; P^T 0] [w; c] = [f; 0],   P = [1, x],      s(y) = sum_j w_j phi(|y - x_j|) + c_0 + sum_a c_a y_a
+   -- the standard thin-plate spline ("N + d + 1 with affine augmentation").  P^T w = 0
+   makes Phi w = (Phi + s P P^T) w = B w, so with the SAME shifted SPD matrix B and the same d + 2 right-hand sides
+       w = B^-1 f - B^-1 P c,     (P^T B^-1 P) c = P^T B^-1 f :
+   one MFMA Cholesky, the blocked sweeps, a (d+1) x (d+1) system on the host (routes 9 / 10 mirror 2 / 3).  h_poly
+   receives c in RAW coordinates (the solve uses the standardised columns of poly_block_kernel). */
+static int rbf_solve_affine_lu(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim, size_t xtda,
+                               double *d_phi, size_t lda, double *d_w, double *h_poly);
+
 static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim, size_t xtda,
-                          double *d_phi, size_t lda, double *d_w, int *h_route, bool keep_upper)
+                          double *d_phi, size_t lda, double *d_w, int *h_route, bool keep_upper, double *h_poly)
 {
   REQUIRE(ctx, ctx != NULL, ST_EFAULT);
   HIP_OK(ctx, hipSetDevice(ctx->device));      /* one context per device: bind before any launch */
@@ -191,7 +202,7 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
       st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);
       if (st) return st;
     }
-    hipLaunchKernelGGL(poly_block_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_x, n, dim, xtda, (const double *)d_w, Y, Pk);
+    hipLaunchKernelGGL(poly_block_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_x, n, dim, xtda, (const double *)d_w, Y, Pk, G + 24);
     HIP_OK(ctx, hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const double *)d_phi, lda, n, d_norm);
     hipLaunchKernelGGL(poly_shift_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, d_phi, lda, n,
@@ -203,16 +214,39 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
     hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(k * (k + 1))), dim3(256), 0, ctx->stream, (const double *)Pk, (const double *)Y,
                        n, k, G);
     LAUNCH_CHECK(ctx);
-    double hG[SV_MAXK * (SV_MAXK + 1)];
+    /* one read-back: the Gram block, the column statistics (G + 24) and the norm (G + 32) are neighbours */
+    double hbuf[40];
     unsigned long long hnorm = 0;
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_OK(ctx, hipMemcpy(hG, G, sizeof(double) * k * (k + 1), hipMemcpyDeviceToHost));
+    HIP_OK(ctx, hipMemcpy(hbuf, G, sizeof(double) * 33, hipMemcpyDeviceToHost));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_OK(ctx, hipMemcpy(&hnorm, d_norm, sizeof hnorm, hipMemcpyDeviceToHost));
-    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    const double *hG = hbuf;
+    memcpy(&hnorm, &hbuf[32], sizeof hnorm);
     double nrm;
     memcpy(&nrm, &hnorm, sizeof nrm);
     const double s = cmul * nrm / (double)n;
+    if (h_poly) {
+      /* (P^T B^-1 P) c = P^T B^-1 f, w = B^-1 f - B^-1 P c */
+      double M[SV_MAXK * SV_MAXK], g[SV_MAXK];
+      for (int a = 0; a < k; a++) {
+        g[a] = hG[a * (k + 1)];
+        for (int b = 0; b < k; b++) M[a * k + b] = hG[a * (k + 1) + 1 + b];
+      }
+      if (host_solve(k, M, g)) break;             /* degenerate (collinear centres): the reference route reports it */
+      double neg[SV_MAXK];
+      for (int a = 0; a < k; a++) neg[a] = -g[a];
+      HIP_OK(ctx, hipMemcpyAsync(G, neg, sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)Y, n, k,
+                         (const double *)G, d_w);
+      LAUNCH_CHECK(ctx);
+      HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   /* neg[] is a stack buffer */
+      /* standardised columns (x - mean) inv  ->  raw coordinates */
+      const double *mean = hbuf + 24, *inv = hbuf + 27;
+      h_poly[0] = g[0];
+      for (int a = 0; a < dim; a++) { h_poly[1 + a] = g[1 + a] * inv[a]; h_poly[0] -= g[1 + a] * inv[a] * mean[a]; }
+      if (h_route) *h_route = 9;
+      return ST_SUCCESS;
+    }
     /* S c = g with S = I/s - P^T B^-1 P, g = P^T B^-1 f   (G column 0 = g, columns 1..k = P^T B^-1 P) */
     double S[SV_MAXK * SV_MAXK], g[SV_MAXK];
     for (int a = 0; a < k; a++) {
@@ -230,6 +264,11 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
   }
 
   /* ---- reference route: pivoted LU */
+  if (h_poly) {
+    st = rbf_solve_affine_lu(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, h_poly);
+    if (!st && h_route) *h_route = 10;
+    return st;
+  }
   st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);
   if (st) return st;
   int *d_perm = (int *)Pk;                         /* n ints fit in the k*n doubles of Pk */
@@ -238,6 +277,103 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
   if (st) return st;
   if (h_route) *h_route = 3;
   return gsl_sinterp_hip_lu_svx(ctx, n, d_phi, lda, d_perm, d_w);
+}
+
+
+/* border of the augmented matrix: rows / columns n .. n+k-1 = [1, x] (raw coordinates), zero corner; rhs tail = 0 */
+__global__ void __launch_bounds__(256)
+affine_border_kernel(double *__restrict__ phi, size_t lda, size_t n, const double *__restrict__ x, int dim, size_t xtda,
+                     double *__restrict__ rhs)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int k = dim + 1;
+  if (i < n) {
+    for (int a = 0; a < k; a++) {
+      const double v = a == 0 ? 1.0 : x[i * xtda + a - 1];
+      phi[i * lda + n + a] = v;
+      phi[(n + a) * lda + i] = v;
+    }
+  }
+  if (i < (size_t)k) {
+    for (int a = 0; a < k; a++) phi[(n + i) * lda + n + a] = 0.0;
+    rhs[n + i] = 0.0;
+  }
+}
+
+/* the reference route of the augmented system: gsl_linalg_LU_decomp + _svx (linalg/lu.c:59-201) of the (n + d + 1) matrix */
+static int rbf_solve_affine_lu(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim, size_t xtda,
+                               double *d_phi, size_t lda, double *d_w, double *h_poly)
+{
+  const int k = dim + 1;
+  const size_t na = n + (size_t)k;
+  if (lda < na) return sinterp_fail(ctx, ST_EINVAL, "rbf_solve_affine: the pivoted-LU route needs d_phi with n + dim + 1 rows and lda >= n + dim + 1", hipSuccess, __FILE__, __LINE__);
+  int st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);
+  if (st) return st;
+  double *d_rhs = NULL;
+  int *d_perm = NULL;
+  st = gsl_sinterp_hip_malloc(ctx, (void **)&d_rhs, na * sizeof(double));
+  if (!st) st = gsl_sinterp_hip_malloc(ctx, (void **)&d_perm, na * sizeof(int));
+  if (!st) {
+    hipError_t e = hipMemcpyAsync(d_rhs, d_w, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) st = sinterp_fail(ctx, ST_EFAILED, "rbf_solve_affine: copy", e, __FILE__, __LINE__);
+  }
+  if (!st) {
+    hipLaunchKernelGGL(affine_border_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_phi, lda, n, d_x, dim, xtda, d_rhs);
+    if (hipGetLastError() != hipSuccess) st = sinterp_fail(ctx, ST_EFAILED, "rbf_solve_affine: border", hipSuccess, __FILE__, __LINE__);
+  }
+  int signum = 0;
+  if (!st) st = gsl_sinterp_hip_lu_decomp(ctx, na, d_phi, lda, d_perm, &signum);
+  if (!st) st = gsl_sinterp_hip_lu_svx(ctx, na, d_phi, lda, d_perm, d_rhs);
+  if (!st) {
+    hipError_t e = hipMemcpyAsync(d_w, d_rhs, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(h_poly, d_rhs + n, (size_t)k * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) st = sinterp_fail(ctx, ST_EFAILED, "rbf_solve_affine: read back", e, __FILE__, __LINE__);
+  }
+  gsl_sinterp_hip_free(ctx, d_rhs); gsl_sinterp_hip_free(ctx, d_perm);
+  return st;
+}
+
+extern "C" int gsl_sinterp_hip_rbf_solve_affine(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim,
+                                                size_t xtda, double *d_phi, size_t lda, double *d_w, double *h_poly, int *h_route)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, kind == GSL_SINTERP_RBF_TPS, ST_EINVAL);      /* conditionally positive definite of order 2: the kernel the tail belongs to */
+  REQUIRE(ctx, h_poly != NULL, ST_EFAULT);
+  REQUIRE(ctx, n >= (size_t)dim + 1, ST_EINVAL);
+  for (int a = 0; a < SV_MAXK; a++) h_poly[a] = 0.0;
+  return rbf_solve_impl(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, d_w, h_route, false, h_poly);
+}
+
+/* s[k] += c_0 + sum_a c_a y[k][a] */
+__global__ void __launch_bounds__(256)
+add_poly_kernel(double *__restrict__ s, size_t m, const double *__restrict__ y, size_t ytda, int dim, double c0, double c1, double c2,
+                double c3)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+    double t = fma(c1, y[k * ytda], c0);
+    if (dim > 1) t = fma(c2, y[k * ytda + 1], t);
+    if (dim > 2) t = fma(c3, y[k * ytda + 2], t);
+    s[k] = s[k] + t;
+  }
+}
+
+extern "C" int gsl_sinterp_hip_rbf_eval_affine(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *h_poly, const double *d_x,
+                                               size_t n, int dim, size_t xtda, const double *d_w, const double *d_y, size_t m,
+                                               size_t ytda, double *d_s, unsigned long long model_id)
+{
+  REQUIRE(ctx, ctx != NULL, ST_EFAULT);
+  REQUIRE(ctx, h_poly != NULL, ST_EFAULT);
+  int st = gsl_sinterp_hip_rbf_eval_model(ctx, kind, eps, d_x, n, dim, xtda, d_w, d_y, m, ytda, d_s, model_id);
+  if (st || m == 0) return st;
+  size_t blocks = (m + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_poly_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_s, m, d_y, ytda, dim, h_poly[0], h_poly[1],
+                     dim > 1 ? h_poly[2] : 0.0, dim > 2 ? h_poly[3] : 0.0);
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
 }
 
 

@@ -530,6 +530,9 @@ typedef struct {
   /* ordinary kriging (gsl_sinterp_kriging): the kernel is the covariance, `mean` the estimated mean added by every sweep */
   int krige;
   double mean;
+  /* thin-plate spline with its affine tail (gsl_sinterp_rbf_tps_affine): c_0 + sum_a c_a y_a added by every sweep */
+  int affine;
+  double poly[4];
 } rbf_state;
 
 static unsigned long long next_model_id(void)
@@ -548,6 +551,12 @@ static void *rbf_alloc_kind(int kind, size_t dim, size_t size)
 static void *rbf_gauss_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_GAUSSIAN, dim, size); }
 static void *rbf_tps_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_TPS, dim, size); }
 static void *rbf_wendland_alloc(size_t dim, size_t size) { return rbf_alloc_kind(GSL_SINTERP_RBF_WENDLAND, dim, size); }
+static void *rbf_tps_affine_alloc(size_t dim, size_t size)
+{
+  rbf_state *st = (rbf_state *)rbf_alloc_kind(GSL_SINTERP_RBF_TPS, dim, size);
+  if (st) st->affine = 1;
+  return st;
+}
 static void *krige_alloc(size_t dim, size_t size)
 {
   rbf_state *st = (rbf_state *)rbf_alloc_kind(GSL_SINTERP_RBF_GAUSSIAN, dim, size);      /* Gaussian covariance */
@@ -604,16 +613,20 @@ static int rbf_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *
   const size_t model_bytes = n * (dim + 1) * sizeof(double);
   double *d_phi = NULL;
   int route = 0;
-  s = gsl_sinterp_hip_malloc(c, (void **)&d_phi, n * n * sizeof(double));
+  /* affine thin-plate spline: room for the (n + d + 1) augmented matrix of the pivoted-LU route (lda even) */
+  const size_t lda = st->affine ? ((n + dim + 2) & ~(size_t)1) : n, phi_rows = st->affine ? n + dim + 1 : n;
+  s = gsl_sinterp_hip_malloc(c, (void **)&d_phi, phi_rows * lda * sizeof(double));
   if (!s) s = gsl_sinterp_hip_h2d(c, st->d_x, h_x, n * dim * sizeof(double));
   if (!s) s = gsl_sinterp_hip_h2d(c, st->d_w, h_f, n * sizeof(double));
   /* fill + dense solve on the device: Cholesky (Gaussian), shifted-SPD Cholesky with a
      Woodbury correction or pivoted LU (thin-plate spline) -- csrc/hip/solve.hip */
   double rcond = GSL_NAN;
   if (!s && st->krige)
-    s = gsl_sinterp_hip_krige_solve(c, st->kind, st->eps, interp->nugget, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, &st->mean, &route);
+    s = gsl_sinterp_hip_krige_solve(c, st->kind, st->eps, interp->nugget, st->d_x, n, (int)dim, dim, d_phi, lda, st->d_w, &st->mean, &route);
+  else if (!s && st->affine)
+    s = gsl_sinterp_hip_rbf_solve_affine(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, lda, st->d_w, st->poly, &route);
   else if (!s)
-    s = gsl_sinterp_hip_rbf_solve_ex(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, n, st->d_w, interp->solver,
+    s = gsl_sinterp_hip_rbf_solve_ex(c, st->kind, st->eps, st->d_x, n, (int)dim, dim, d_phi, lda, st->d_w, interp->solver,
                                      interp->want_rcond ? &rcond : NULL, &route);
   interp->rcond = rcond; interp->route = route;
   /* replicate the solved model: ONE broadcast of the weight vector (+ centres) */
@@ -665,6 +678,18 @@ static int rbf_prepare_devices(gsl_sinterp *interp, rbf_state *st)
   return GSL_SUCCESS;
 }
 
+/* the sweep of an RBF-type model on context c (plain, + kriging mean, + affine tail) */
+static int rbf_sweep(const rbf_state *st, gsl_sinterp_hip_ctx *c, const double *d_x, const double *d_w, const double *d_y, size_t m,
+                     size_t ytda, double *d_s)
+{
+  if (st->krige)
+    return gsl_sinterp_hip_krige_eval(c, st->kind, st->eps, st->mean, d_x, st->n, (int)st->dim, st->dim, d_w, d_y, m, ytda, d_s, st->model_id);
+  if (st->affine)
+    return gsl_sinterp_hip_rbf_eval_affine(c, st->kind, st->eps, st->poly, d_x, st->n, (int)st->dim, st->dim, d_w, d_y, m, ytda, d_s,
+                                           st->model_id);
+  return gsl_sinterp_hip_rbf_eval_model(c, st->kind, st->eps, d_x, st->n, (int)st->dim, st->dim, d_w, d_y, m, ytda, d_s, st->model_id);
+}
+
 static int rbf_eval_resident(const gsl_sinterp *interp, const double *d_y, size_t m, size_t ytda,
                              double *d_s, int *d_leaf)
 {
@@ -673,13 +698,7 @@ static int rbf_eval_resident(const gsl_sinterp *interp, const double *d_y, size_
   if (!st->d_w) GSL_ERROR("gsl_sinterp_eval: interpolant not initialised", GSL_EINVAL);
   /* resident buffers live on ONE device: member 0 evaluates them (shard resident targets yourself with
      gsl_sinterp_hip_shard_bounds + one interpolant per device, as bench.py does per process) */
-  if (!st->krige) {
-    HIP_TRY(gsl_sinterp_hip_rbf_eval_model(st->ctx, st->kind, st->eps, st->d_x, st->n, (int)st->dim, st->dim, st->d_w, d_y, m, ytda, d_s,
-                                           st->model_id), st->ctx);
-    return GSL_SUCCESS;
-  }
-  HIP_TRY(gsl_sinterp_hip_krige_eval(st->ctx, st->kind, st->eps, st->mean, st->d_x, st->n, (int)st->dim, st->dim,
-                                     st->d_w, d_y, m, ytda, d_s, st->model_id), st->ctx);
+  HIP_TRY(rbf_sweep(st, st->ctx, st->d_x, st->d_w, d_y, m, ytda, d_s), st->ctx);
   return GSL_SUCCESS;
 }
 
@@ -688,11 +707,7 @@ static int rbf_shard_eval(void *state, int member, const double *d_y, size_t m, 
   (void)d_leaf;
   rbf_state *st = (rbf_state *)state;
   const double *model = st->m_model[member];
-  if (st->krige)
-    return gsl_sinterp_hip_krige_eval(gsl_sinterp_hip_group_ctx(st->ss.grp, member), st->kind, st->eps, st->mean, model, st->n,
-                                      (int)st->dim, st->dim, model + st->n * st->dim, d_y, m, st->dim, d_s, st->model_id);
-  return gsl_sinterp_hip_rbf_eval_model(gsl_sinterp_hip_group_ctx(st->ss.grp, member), st->kind, st->eps, model, st->n, (int)st->dim,
-                                        st->dim, model + st->n * st->dim, d_y, m, st->dim, d_s, st->model_id);
+  return rbf_sweep(st, gsl_sinterp_hip_group_ctx(st->ss.grp, member), model, model + st->n * st->dim, d_y, m, st->dim, d_s);
 }
 
 static int rbf_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vector *sv, int *leaf)
@@ -718,8 +733,7 @@ static int rbf_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vec
   int s = gsl_sinterp_hip_malloc(c, (void **)&d_y, m * dim * sizeof(double));
   if (!s) s = gsl_sinterp_hip_malloc(c, (void **)&d_s, m * sizeof(double));
   if (!s) s = gsl_sinterp_hip_h2d(c, d_y, h_y, m * dim * sizeof(double));
-  if (!s && st->krige) s = gsl_sinterp_hip_krige_eval(c, st->kind, st->eps, st->mean, st->d_x, st->n, (int)dim, dim, st->d_w, d_y, m, dim, d_s, st->model_id);
-  else if (!s) s = gsl_sinterp_hip_rbf_eval_model(c, st->kind, st->eps, st->d_x, st->n, (int)dim, dim, st->d_w, d_y, m, dim, d_s, st->model_id);
+  if (!s) s = rbf_sweep(st, c, st->d_x, st->d_w, d_y, m, dim, d_s);
   if (!s) s = gsl_sinterp_hip_d2h(c, h_s, d_s, m * sizeof(double));
   if (!s) for (size_t k = 0; k < m; k++) gsl_vector_set(sv, k, h_s[k]);
   if (!s && leaf) for (size_t k = 0; k < m; k++) leaf[k] = -1;
@@ -814,6 +828,8 @@ static const gsl_sinterp_type gauss_type = {"rbf-gaussian", 1, &rbf_gauss_alloc,
 static const gsl_sinterp_type tps_type = {"rbf-thin-plate-spline", 1, &rbf_tps_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
 static const gsl_sinterp_type simplex_type = {"linear-simplex", 3, &simplex_alloc, &simplex_init, &simplex_eval_many, &simplex_eval_resident, &simplex_free};
 static const gsl_sinterp_type wendland_type = {"rbf-wendland-c2", 1, &rbf_wendland_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
+static const gsl_sinterp_type tps_affine_type = {"rbf-thin-plate-spline-affine", 3, &rbf_tps_affine_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
+const gsl_sinterp_type *gsl_sinterp_rbf_tps_affine = &tps_affine_type;
 static const gsl_sinterp_type krige_type = {"ordinary-kriging-gaussian", 1, &krige_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
 const gsl_sinterp_type *gsl_sinterp_kriging = &krige_type;
 const gsl_sinterp_type *gsl_sinterp_rbf_wendland = &wendland_type;
@@ -898,6 +914,17 @@ int gsl_sinterp_set_nugget(gsl_sinterp *interp, double nugget)
   return GSL_SUCCESS;
 }
 
+int gsl_sinterp_poly(const gsl_sinterp *interp, gsl_vector *c)
+{
+  if (!interp || !c) GSL_ERROR("gsl_sinterp_poly: null argument", GSL_EFAULT);
+  if (interp->type != &tps_affine_type) GSL_ERROR("gsl_sinterp_poly: affine thin-plate-spline interpolants only", GSL_EINVAL);
+  const rbf_state *st = (const rbf_state *)interp->state;
+  if (!st->d_w) GSL_ERROR("gsl_sinterp_poly: interpolant not initialised", GSL_EINVAL);
+  if (c->size != st->dim + 1) GSL_ERROR("gsl_sinterp_poly: vector length must be dim + 1", GSL_EBADLEN);
+  for (size_t a = 0; a <= st->dim; a++) gsl_vector_set(c, a, st->poly[a]);
+  return GSL_SUCCESS;
+}
+
 int gsl_sinterp_mean(const gsl_sinterp *interp, double *mean)
 {
   if (!interp || !mean) GSL_ERROR("gsl_sinterp_mean: null argument", GSL_EFAULT);
@@ -914,6 +941,10 @@ int gsl_sinterp_set_solver(gsl_sinterp *interp, int solver)
   if (solver < GSL_SINTERP_SOLVER_DEFAULT || solver > GSL_SINTERP_SOLVER_LU_REFINE)
     GSL_ERROR("gsl_sinterp_set_solver: unknown solver", GSL_EINVAL);
   if (interp->type == &simplex_type) GSL_ERROR("gsl_sinterp_set_solver: not an RBF interpolant", GSL_EINVAL);
+  /* kriging and the affine thin-plate spline solve saddle systems on routes of their own (7 / 8, 9 / 10): accepting a
+     solver here and ignoring it at init would be a silent no-op */
+  if ((interp->type == &krige_type || interp->type == &tps_affine_type) && solver != GSL_SINTERP_SOLVER_DEFAULT)
+    GSL_ERROR("gsl_sinterp_set_solver: kriging / affine thin-plate-spline interpolants choose their own route", GSL_EINVAL);
   if (interp->type == &tps_type && (solver == GSL_SINTERP_SOLVER_CHOLESKY2 || solver == GSL_SINTERP_SOLVER_PCHOLESKY))
     GSL_ERROR("gsl_sinterp_set_solver: the thin-plate-spline matrix is indefinite (zero diagonal): no Cholesky-type solver", GSL_EINVAL);
   interp->solver = solver;
@@ -923,6 +954,8 @@ int gsl_sinterp_set_solver(gsl_sinterp *interp, int solver)
 int gsl_sinterp_set_rcond(gsl_sinterp *interp, int want)
 {
   if (!interp) GSL_ERROR("gsl_sinterp_set_rcond: null interpolant", GSL_EFAULT);
+  if (want && (interp->type == &krige_type || interp->type == &tps_affine_type))
+    GSL_ERROR("gsl_sinterp_set_rcond: no condition estimate on the kriging / affine thin-plate-spline routes", GSL_EINVAL);
   interp->want_rcond = want != 0;
   return GSL_SUCCESS;
 }
@@ -1095,7 +1128,7 @@ static const char INTERP_MAGIC[8] = {'G', 'S', 'L', 'S', 'I', 'N', 'T', '1'};
 
 static int type_id(const gsl_sinterp_type *T)
 {
-  return T == &gauss_type ? 0 : (T == &tps_type ? 1 : (T == &wendland_type ? 3 : (T == &krige_type ? 4 : 2)));
+  return T == &gauss_type ? 0 : (T == &tps_type ? 1 : (T == &wendland_type ? 3 : (T == &krige_type ? 4 : (T == &tps_affine_type ? 5 : 2))));
 }
 
 int gsl_sinterp_fwrite(FILE *stream, const gsl_sinterp *interp)
@@ -1128,7 +1161,8 @@ int gsl_sinterp_fwrite(FILE *stream, const gsl_sinterp *interp)
   if (st->krige) memcpy(&flags, &st->mean, sizeof flags);                       /* kriging: the word carries the mean's bits */
   if (!s && (fwrite(INTERP_MAGIC, 1, 8, stream) != 8 || fwrite(head, sizeof head[0], 3, stream) != 3 ||
              fwrite(&st->eps, sizeof st->eps, 1, stream) != 1 || fwrite(&flags, sizeof flags, 1, stream) != 1 ||
-             fwrite(h, sizeof(double), cnt, stream) != cnt)) {
+             fwrite(h, sizeof(double), cnt, stream) != cnt ||
+             (st->affine && fwrite(st->poly, sizeof(double), 4, stream) != 4))) {      /* affine tail: c_0 .. c_3 behind the weights */
     free(h);
     GSL_ERROR("fwrite failed", GSL_EFAILED);
   }
@@ -1176,10 +1210,13 @@ int gsl_sinterp_fread(FILE *stream, gsl_sinterp *interp)
   double *h = (double *)malloc(cnt * sizeof(double));
   if (!h) GSL_ERROR("gsl_sinterp_fread: out of memory", GSL_ENOMEM);
   if (fread(h, sizeof(double), cnt, stream) != cnt) { free(h); GSL_ERROR("fread failed", GSL_EFAILED); }
+  double poly[4] = {0.0, 0.0, 0.0, 0.0};
+  if (st->affine && fread(poly, sizeof(double), 4, stream) != 4) { free(h); GSL_ERROR("fread failed", GSL_EFAILED); }
   int s = rbf_prepare_devices(interp, st);
   if (s) { free(h); return s; }
   st->eps = eps;
   if (st->krige) memcpy(&st->mean, &flags, sizeof st->mean);
+  if (st->affine) memcpy(st->poly, poly, sizeof poly);
   st->model_id = next_model_id();
   s = gsl_sinterp_hip_h2d(st->ctx, st->d_x, h, cnt * sizeof(double));
   if (!s && st->ss.grp) s = gsl_sinterp_hip_group_broadcast(st->ss.grp, (void *const *)st->m_model, cnt * sizeof(double));

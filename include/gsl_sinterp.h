@@ -260,6 +260,9 @@ struct gsl_sinterp_struct {
 
 extern const gsl_sinterp_type *gsl_sinterp_rbf_gaussian;
 extern const gsl_sinterp_type *gsl_sinterp_rbf_tps;
+/* the thin-plate spline with its affine tail: s(y) = sum_j w_j phi(|y - x_j|) + c_0 + sum_a c_a y_a with P^T w = 0
+   (the (N + d + 1) saddle system; reproduces linear data exactly).  gsl_sinterp_poly reads c back. */
+extern const gsl_sinterp_type *gsl_sinterp_rbf_tps_affine;
 extern const gsl_sinterp_type *gsl_sinterp_rbf_wendland;    /* compactly supported C2 kernel (README:18-26 future list) */
 extern const gsl_sinterp_type *gsl_sinterp_linear_simplex;
 /* ordinary kriging with a Gaussian covariance exp(-(eps h)^2) and an optional nugget (README:24 future list):
@@ -285,6 +288,7 @@ int gsl_sinterp_set_shape(gsl_sinterp *interp, double eps);
    with gsl_sinterp_rcond (GSL_EINVAL when none is available). */
 int gsl_sinterp_set_nugget(gsl_sinterp *interp, double nugget);     /* kriging type only (GSL_EINVAL otherwise) */
 int gsl_sinterp_mean(const gsl_sinterp *interp, double *mean);     /* the estimated mean mu of an initialised kriging interpolant */
+int gsl_sinterp_poly(const gsl_sinterp *interp, gsl_vector *c);    /* c_0 .. c_dim of an initialised gsl_sinterp_rbf_tps_affine interpolant */
 int gsl_sinterp_set_solver(gsl_sinterp *interp, int solver);
 int gsl_sinterp_set_rcond(gsl_sinterp *interp, int want);
 int gsl_sinterp_rcond(const gsl_sinterp *interp, double *rcond);

@@ -217,6 +217,19 @@ int gsl_sinterp_hip_rbf_solve_ex(gsl_sinterp_hip_ctx *ctx, int kind, double eps,
                                  size_t xtda, double *d_phi, size_t lda, double *d_w, int solver, double *h_rcond,
                                  int *h_route);
 
+/* Thin-plate spline WITH its affine tail (the "N + d + 1" system):
+       [Phi P; P^T 0] [w; c] = [f; 0],  P = [1, x],     s(y) = sum_j w_j phi(|y - x_j|) + c_0 + sum_a c_a y_a.
+   d_w holds f on entry and w on exit, h_poly[0 .. dim] receives c (raw coordinates).  Route 9: block elimination on the
+   shifted SPD matrix of route 2 (one MFMA Cholesky, d + 2 right-hand sides, a (d+1) x (d+1) system on the host);
+   route 10: pivoted LU of the augmented matrix (the reference route, linalg/lu.c:59-201; taken when the shifted
+   matrix is not SPD or GSL_SINTERP_FORCE_LU=1) -- it needs d_phi with n + dim + 1 rows and lda >= n + dim + 1.
+   kind must be GSL_SINTERP_RBF_TPS.  gsl_sinterp_hip_rbf_eval_affine = the RBF sweep + the polynomial. */
+int gsl_sinterp_hip_rbf_solve_affine(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim,
+                                     size_t xtda, double *d_phi, size_t lda, double *d_w, double *h_poly, int *h_route);
+int gsl_sinterp_hip_rbf_eval_affine(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *h_poly, const double *d_x,
+                                    size_t n, int dim, size_t xtda, const double *d_w, const double *d_y, size_t m,
+                                    size_t ytda, double *d_s, unsigned long long model_id);
+
 /* Ordinary kriging on a positive definite kernel used as covariance (GAUSSIAN or WENDLAND) with a nugget >= 0 (the
    reference's README:24 future list): d_w holds f on entry and the dual weights w on exit, *h_mean the estimated
    mean mu; s(y) = mu + sum_j w_j phi(|y - x_j|) (gsl_sinterp_hip_krige_eval = the RBF sweep + mu).  Route 7: Cholesky

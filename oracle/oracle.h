@@ -153,6 +153,11 @@ int oracle_rbf_solve(int kind, double eps, const double *x, size_t n, int dim, s
 void oracle_rbf_eval(int kind, double eps, const double *x, size_t n, int dim, size_t tda,
                      const double *w, const double *y, size_t m, size_t ytda, double *s);
 
+/* thin-plate spline with its affine tail: pivoted LU of the (n + dim + 1) saddle system; c[0 .. dim] in raw coordinates */
+int oracle_rbf_solve_affine(int kind, double eps, const double *x, size_t n, int dim, size_t tda,
+                            const double *f, double *w, double *c);
+void oracle_rbf_eval_affine(int kind, double eps, const double *c, const double *x, size_t n, int dim, size_t tda,
+                            const double *w, const double *y, size_t m, size_t ytda, double *s);
 /* ordinary kriging (dual form) on the same kernels: K = Phi + nugget I, Cholesky (pivoted LDL^T when K is only
    semi-definite); no reference code (README:24), parity unpinned */
 int oracle_krige_solve(int kind, double eps, double nugget, const double *x, size_t n, int dim, size_t tda,

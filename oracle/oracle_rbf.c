@@ -117,3 +117,46 @@ void oracle_krige_eval(int kind, double eps, double mean, const double *x, size_
   oracle_rbf_eval(kind, eps, x, n, dim, tda, w, y, m, ytda, s);
   for (size_t k = 0; k < m; k++) s[k] = s[k] + mean;
 }
+
+/* Thin-plate spline with its affine tail ("N + d + 1 with affine augmentation"; no
+   reference code, PARITY UNPINNED): the saddle system
+       [Phi P; P^T 0] [w; c] = [f; 0],   P = [1, x] in raw coordinates,
+   solved the way the reference would solve an indefinite system: gsl_linalg_LU_decomp + _svx (linalg/lu.c:59-201,
+   pinned) of the full (n + dim + 1) matrix;  s(y) = sum_j w_j phi(|y - x_j|) (j ascending) + c_0 + sum_a c_a y_a. */
+int oracle_rbf_solve_affine(int kind, double eps, const double *x, size_t n, int dim, size_t tda,
+                            const double *f, double *w, double *c)
+{
+  const size_t k = (size_t)dim + 1, na = n + k;
+  double *a = (double *)calloc(na * na, sizeof(double)), *rhs = (double *)calloc(na, sizeof(double));
+  size_t *perm = (size_t *)malloc(na * sizeof(size_t));
+  if (!a || !rhs || !perm) { free(a); free(rhs); free(perm); return ORACLE_FAILURE; }
+  oracle_rbf_fill(kind, eps, x, n, dim, tda, a, na);
+  for (size_t i = 0; i < n; i++) {
+    for (size_t q = 0; q < k; q++) {
+      const double v = q == 0 ? 1.0 : x[i * tda + q - 1];
+      a[i * na + n + q] = v;
+      a[(n + q) * na + i] = v;
+    }
+    rhs[i] = f[i];
+  }
+  int signum;
+  int status = oracle_lu_decomp(na, a, na, perm, &signum);
+  if (status == ORACLE_SUCCESS) status = oracle_lu_svx(na, a, na, perm, rhs);
+  if (status == ORACLE_SUCCESS) {
+    memcpy(w, rhs, n * sizeof(double));
+    for (size_t q = 0; q < k; q++) c[q] = rhs[n + q];
+  }
+  free(a); free(rhs); free(perm);
+  return status;
+}
+
+void oracle_rbf_eval_affine(int kind, double eps, const double *c, const double *x, size_t n, int dim, size_t tda,
+                            const double *w, const double *y, size_t m, size_t ytda, double *s)
+{
+  oracle_rbf_eval(kind, eps, x, n, dim, tda, w, y, m, ytda, s);
+  for (size_t k = 0; k < m; k++) {
+    double t = c[0];
+    for (int a = 0; a < dim; a++) t += c[1 + a] * y[k * ytda + a];
+    s[k] = s[k] + t;
+  }
+}

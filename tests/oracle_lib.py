@@ -272,6 +272,26 @@ def krige_solve(kind, eps, nugget, x, f):
     return w, mu.value
 
 
+def rbf_solve_affine(kind, eps, x, f):
+    """thin-plate spline with its affine tail: weights w and c_0 .. c_dim (raw coordinates)"""
+    n, d = x.shape
+    w = np.empty(n)
+    c = np.zeros(d + 1)
+    st = lib().oracle_rbf_solve_affine(kind, C.c_double(eps), _p(x), _sz(n), d, _sz(x.strides[0] // 8), _p(f), _p(w), _p(c))
+    assert st == 0, st
+    return w, c
+
+
+def rbf_eval_affine(kind, eps, c, x, w, y):
+    n, d = x.shape
+    m = y.shape[0]
+    s = np.empty(m)
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    lib().oracle_rbf_eval_affine(kind, C.c_double(eps), _p(c), _p(x), _sz(n), d, _sz(x.strides[0] // 8), _p(w), _p(y), _sz(m),
+                                 _sz(y.strides[0] // 8), _p(s))
+    return s
+
+
 def krige_eval(kind, eps, mean, x, w, y):
     return rbf_eval(kind, eps, x, w, y) + mean
 

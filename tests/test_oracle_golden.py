@@ -300,3 +300,22 @@ def test_wendland_kernel_properties(orc, dim):
     f = orc.synth_response(x)
     w = orc.rbf_solve(2, eps, x, f)
     assert np.abs(orc.rbf_eval(2, eps, x, w, x) - f).max() < 1e-10 * max(1.0, np.abs(f).max())
+
+
+@pytest.mark.parametrize("dim,n", [(1, 40), (2, 150), (3, 120)])
+def test_affine_thin_plate_spline_properties(orc, dim, n):
+    """The affine-augmented thin-plate spline of the oracle (pivoted LU of the (n + d + 1) saddle system; no reference
+    code: parity unpinned) by the properties that define it: it interpolates the data, its weights are orthogonal to
+    the affine polynomials (P^T w = 0), and affine data are reproduced by the tail alone (w = 0)."""
+    x = orc.synth_centres(n, dim)
+    f = orc.synth_response(x)
+    w, c = orc.rbf_solve_affine(1, 0.0, x, f)
+    assert np.abs(orc.rbf_eval_affine(1, 0.0, c, x, w, x) - f).max() < 1e-10
+    P = np.hstack([np.ones((n, 1)), x])
+    assert np.abs(P.T @ w).max() < 1e-9 * max(1.0, np.abs(w).max())
+    coef = np.arange(1, dim + 2) * 0.5
+    lin = P @ coef
+    w2, c2 = orc.rbf_solve_affine(1, 0.0, x, lin)
+    assert np.abs(w2).max() < 1e-9 and np.abs(c2 - coef).max() < 1e-10
+    y = orc.synth_targets(0, 200, dim)
+    assert np.abs(orc.rbf_eval_affine(1, 0.0, c2, x, w2, y) - (np.hstack([np.ones((200, 1)), y]) @ coef)).max() < 1e-10
