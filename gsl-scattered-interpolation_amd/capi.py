@@ -201,6 +201,7 @@ SIGNATURES = {
     "simplex_mesh_tree_nodes": (_pi, [_vp]),
     "simplex_mesh_geometry": (None, [_vp, _pd, _pd]),
     "simplex_mesh_set_convex": (None, [_vp, _i]),
+    "simplex_mesh_convex": (_i, [_vp]),
     "simplex_mesh_device_alloc": (_vp, [_vp, _i]),
     "simplex_mesh_device_free": (None, [_vp]),
     "simplex_mesh_device_set_response": (_i, [_vp, _pv]),
@@ -712,6 +713,9 @@ class SimplexMesh:
 
     def set_convex(self, convex):
         lib().simplex_mesh_set_convex(self._h, int(convex))
+
+    def convex(self):
+        return bool(lib().simplex_mesh_convex(self._h))
 
     def device_alloc(self, device=0):
         h = lib().simplex_mesh_device_alloc(self._h, device)

@@ -178,14 +178,10 @@ __device__ __forceinline__ void diag128_forward(const double *S, const double *D
       if (half == 0) t[r] = y[i * 32 + r] - sum;
       __builtin_amdgcn_wave_barrier();
       /* y_i = Dinv_i t  (Dinv lower triangular: exact zeros above the diagonal) */
-      const double *Wr = Dv + i * PBLK + r * PQ + half * 16;
+      const double *Wr = Dv + i * PBLK + (half * 16) * PQ + r;           /* Dinv[r][c] = Dt[c * PQ + r] (stored transposed) */
       double acc = 0.0;
 #pragma unroll
-      for (int c = 0; c < 16; c += 2) {
-        const double2 w2 = *reinterpret_cast<const double2 *>(Wr + c);
-        acc = fma(w2.x, t[half * 16 + c], acc);
-        acc = fma(w2.y, t[half * 16 + c + 1], acc);
-      }
+      for (int c = 0; c < 16; c++) acc = fma(Wr[c * PQ], t[half * 16 + c], acc);
       acc += __shfl_xor(acc, 32);
       if (half == 0) y[i * 32 + r] = acc;
       __builtin_amdgcn_wave_barrier();
@@ -222,6 +218,8 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
 #pragma unroll
     for (int t = 0; t < 40; t++) S[(t >> 2) * PBLK + ((t & 3) * 8 + r8) * PQ + k] = v[t];
 #pragma unroll
+    for (int t = 0; t < 16; t++) { const int r = (t & 3) * 8 + r8; Dv[(t >> 2) * PBLK + r * PQ + k] = r == k ? 1.0 : 0.0; }   /* potrf32: identity */
+#pragma unroll
     for (int t = 0; t < 3; t++) { const int e = t * 256 + tid; if (e < nrhs * PB) fs[e] = fv[t]; }
   }
   __syncthreads();
@@ -244,12 +242,12 @@ chol_diag128_kernel(double *__restrict__ A, size_t lda, size_t j0, int *__restri
       const int b = t >> 2, r = (t & 3) * 8 + r8, bi = BI[b], bj = BJ[b];
       const double v = S[b * PBLK + r * PQ + k];
       if (bi != bj || k <= r) Ab[(size_t)(bi * 32 + r) * lda + bj * 32 + k] = v;
-      if (bi == bj) diag_store[(j0 / CB + bi) * (CB * CB) + r * CB + k] = (k <= r) ? v : 0.0;
+      if (bi == bj && diag_store) diag_store[(j0 / CB + bi) * (CB * CB) + r * CB + k] = (k <= r) ? v : 0.0;
     }
 #pragma unroll
     for (int t = 0; t < 16; t++) {
       const int b = t >> 2, r = (t & 3) * 8 + r8;
-      Dinvg[b * 1024 + r * 32 + k] = Dv[b * PBLK + r * PQ + k];
+      Dinvg[b * 1024 + r * 32 + k] = Dv[b * PBLK + k * PQ + r];             /* row-major Dinv from the transposed LDS image */
     }
 #pragma unroll
     for (int t = 0; t < 3; t++) { const int e = t * 256 + tid; if (e < nrhs * PB) fb[(size_t)(e >> 7) * ldf + j0 + (e & 127)] = fs[e]; }
@@ -570,7 +568,10 @@ static int chol_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n,
     double *d_linv = d_diag + ((n + CB - 1) / CB) * (CB * CB);   /* 4 inverted 32x32 blocks */
     const size_t lds_diag = (size_t)(14 * PBLK + TRSV_MAXR * (PB + CB)) * sizeof(double);
     { int ast = sinterp_func_lds(ctx, (const void *)chol_diag128_kernel, (int)lds_diag); if (ast) return ast; }
-    hipLaunchKernelGGL(chol_diag128_kernel, dim3(1), dim3(256), lds_diag, ctx->stream, A, lda, j0, d_info, d_diag, d_linv, fb, ldf, nrhs);
+    /* every panel of this factorisation is 128 wide (n a multiple of 128): the blocks are written straight into A and the
+       write-back launch of the 32-wide path is skipped, so the side copy is not needed either */
+    hipLaunchKernelGGL(chol_diag128_kernel, dim3(1), dim3(256), lds_diag, ctx->stream, A, lda, j0, d_info,
+                       n % PB == 0 ? (double *)NULL : d_diag, d_linv, fb, ldf, nrhs);
     const size_t below = n - j0 - w;
     if (below) {
       /* 16 rows per workgroup while that is at most about one workgroup per CU, 64-row strips above
@@ -681,8 +682,13 @@ static int cholesky_decomp1_impl(gsl_sinterp_hip_ctx *ctx, size_t n, double *d_a
     const unsigned nt = (unsigned)((n + 31) / 32);
     if (!symmetric_input) hipLaunchKernelGGL(tricpy_lower_to_upper_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, d_a, lda, n);
     st = chol_panel(ctx, d_a, lda, n, 0, n, d_info, (double *)d_diag, fb, ldf, nrhs);
-    hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
-                       (const double *)d_diag);
+    {
+      static const bool no_p128w = getenv("GSL_SINTERP_NO_PANEL128") && getenv("GSL_SINTERP_NO_PANEL128")[0] == '1';
+      const bool all128 = !no_p128w && n % PB == 0 && (lda & 1) == 0 && ((((uintptr_t)d_a) & 15) == 0);
+      if (!all128)
+        hipLaunchKernelGGL(chol_diag_writeback_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_a, lda, n,
+                           (const double *)d_diag);
+    }
     int st2 = sinterp_capture_end(ctx, saved, 0, n, lda, d_a, gkey);
     if (me != hipSuccess) return sinterp_fail(ctx, ST_EFAILED, "zero info", me, __FILE__, __LINE__);
     if (st) return st;

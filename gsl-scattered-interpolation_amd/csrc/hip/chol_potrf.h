@@ -10,6 +10,12 @@
 #ifndef TSTAMP
 #define TSTAMP(i) do { } while (0)
 #endif
+/* per-column stamps inside potrf32 serialise its LDS prefetch (s_memtime waits on lgkmcnt): only with -DSINTERP_DIAG_PROF_COLS */
+#if defined(SINTERP_DIAG_PROF_COLS)
+#define TSTAMP_COL(i) TSTAMP(i)
+#else
+#define TSTAMP_COL(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ double lane_bcast(double v, int src)
 {
@@ -77,17 +83,21 @@ __device__ __forceinline__ void frag_store(double *Cb, int fi, int fj, int lane,
 #define PIN_SSV(x, y, z)   asm volatile("" : "+s"(x), "+s"(y), "+v"(z) : : "memory")
 #define PIN_SV(x, y)       asm volatile("" : "+s"(x), "+v"(y) : : "memory")
 
-template <int J>
+/* Columns [K0, K0 + 16) of the 32-wide block: the dot products run over k in [K0, J) only -- the terms k < K0 of the second
+   half were applied to the LDS image by potrf32_split (MFMA), which halves the average dot-product length of the block. */
+#define HB 16
+template <int K0, int J>
 __device__ __forceinline__ void potrf32_step(double (&a)[CB], double vprev, double cur, double inv_prev, double e, double e2, double q,
-                                             const double *D, double *colp, int cstride, const double (&rp)[CB])
+                                             const double *D, double *colp, const double (&rp)[CB])
 {
-  if constexpr (J < CB) {
-    TSTAMP(32 + J);
+  constexpr int END = K0 + HB;
+  if constexpr (J < END) {
+    TSTAMP_COL(32 + J);
     /* ---- head of the chain: d_J and the rsq seed */
     double v, d, uL2 = 0.0, acol = 0.0;
-    if constexpr (J == 0) {
+    if constexpr (J == K0) {
       v = cur;
-      d = lane_bcast(v, 0);
+      d = lane_bcast(v, J);
     } else {
       const double uL = e * inv_prev;                   /* L[J][J-1], uniform */
       d = fma(-uL, uL, q);                              /* uniform; = V_J[J] bit for bit */
@@ -98,32 +108,32 @@ __device__ __forceinline__ void potrf32_step(double (&a)[CB], double vprev, doub
     double y0 = __builtin_amdgcn_rsq(d);
     PIN_V4(y0, v, uL2, acol);
     /* ---- in the shadow of the rsq: column J-1 to the LDS image, the prefetch for the NEXT column's dot product (row
-       J+2's entries k < J: columns <= J-1 are in the image, the store precedes these reads in the wave's in-order
+       J+2's entries K0 <= k < J: columns <= J-1 are in the image, the store precedes these reads in the wave's in-order
        LDS queue), and the two broadcasts of V_J the next column starts from */
-    if constexpr (J > 0) { a[J - 1] = acol; colp[(J - 1) * cstride] = acol; }
+    if constexpr (J > K0) { a[J - 1] = acol; colp[J - 1] = acol; }
     double rn[CB];
-    if constexpr (J + 2 < CB) {
+    if constexpr (J + 2 < END) {
 #pragma unroll
-      for (int k = 0; k < J; k += 2) {
+      for (int k = K0; k < J; k += 2) {
         const double2 t2 = *reinterpret_cast<const double2 *>(D + (J + 2) * PQ + k);
         rn[k] = t2.x;
         if (k + 1 < CB) rn[k + 1] = t2.y;
       }
     }
     double en = 0.0, e2n = 0.0, qn = 0.0, curn = 0.0;
-    if constexpr (J + 1 < CB) en = lane_bcast(v, J + 1);
-    if constexpr (J + 2 < CB) e2n = lane_bcast(v, J + 2);
-    /* ---- partial dot product of column J+1: terms k <= J-1 (two accumulators), then lane J+1's value of it */
-    if constexpr (J + 1 < CB) {
+    if constexpr (J + 1 < END) en = lane_bcast(v, J + 1);
+    if constexpr (J + 2 < END) e2n = lane_bcast(v, J + 2);
+    /* ---- partial dot product of column J+1: terms K0 <= k <= J-1 (two accumulators), then lane J+1's value of it */
+    if constexpr (J + 1 < END) {
       double p0 = a[J + 1], p1 = 0.0;
-      if constexpr (J >= 1) p1 = -acol * uL2;           /* the term k = J-1 opens the second accumulator */
+      if constexpr (J >= K0 + 1) p1 = -acol * uL2;      /* the term k = J-1 opens the second accumulator */
       PIN_SSV(en, e2n, p0);
 #pragma unroll
-      for (int k = 0; k + 1 < J; k++) {
+      for (int k = K0; k + 1 < J; k++) {
         if (k & 1) p1 = fma(-a[k], rp[k], p1);
         else p0 = fma(-a[k], rp[k], p0);
       }
-      curn = (J >= 1) ? p0 + p1 : p0;
+      curn = (J >= K0 + 1) ? p0 + p1 : p0;
       qn = lane_bcast(curn, J + 1);
       PIN_SV(qn, y0);
     }
@@ -131,15 +141,43 @@ __device__ __forceinline__ void potrf32_step(double (&a)[CB], double vprev, doub
        1/sqrt(d) = y0 (1 - r)^(-1/2), r = 1 - d y0^2 with the v_rsq_f64 seed y0 (|r| <~ 2^-21):
        y0 (1 + r/2 + 3 r^2/8) is exact to r^3 ~ 1e-19 -- four dependent ops after the seed.  The diagonal entry
        sqrt(d) = d / sqrt(d) is the SAME product v * inv every row forms (lane J holds v = d); it ends within
-       ~2 ulp of cholesky.c:125-126's sqrt. */
+       ~2 ulp of cholesky.c:125-126's sqrt.  (Moving the store / prefetch / broadcasts into the stalls between these
+       four dependent ops was measured: 22.1 vs 21.2 us per block -- the reads then return too late for the next fill.) */
     const double t = d * y0;
     const double rr = fma(-t, y0, 1.0);
     const double s1 = fma(0.375, rr, 0.5), u = y0 * rr;
     const double inv = fma(u, s1, y0);
-    potrf32_step<J + 1>(a, v, curn, inv, en, e2n, qn, D, colp, cstride, rn);
+    potrf32_step<K0, J + 1>(a, v, curn, inv, en, e2n, qn, D, colp, rn);
   } else {
-    a[CB - 1] = vprev * inv_prev;
-    colp[(CB - 1) * cstride] = a[CB - 1];
+    a[END - 1] = vprev * inv_prev;
+    colp[END - 1] = a[END - 1];
+  }
+}
+
+/* Between the two halves of a potrf32 (same wave, no barrier: the wave's LDS queue is in order): with X = rows 16..31,
+   columns 0..15 of the block (L_10, final) and W = the inverse of the first 16 x 16 block (lanes 32..47 produced it),
+       D[16:32, 16:32]   -=  X X^T          the k < 16 terms of every later column's dot product,
+       Dt[c][16:32]       =  -(X W)[:, c]    the same terms for the inverse columns c < 16
+   -- 8 MFMAs instead of 16 x 16 FMA terms on the wave's in-order issue path.  D: the block (row-major, pitch PQ);
+   Dt: its inverse stored TRANSPOSED (Dt[c * PQ + k] = (L^-1)[k][c]). */
+__device__ __forceinline__ void potrf32_split(double *D, double *Dt, int lane)
+{
+  const int fr = lane & 15, fq = lane >> 4;
+  const double *ap = D + (HB + fr) * PQ + fq;          /* A operand: X[row = fr][k = fq + 4 kk]; also the B operand of X X^T */
+  const double *bp = Dt + fr * PQ + fq;                /* B operand of X W: W[k][c = fr] = Dt[c * PQ + k] */
+  double4_t cu, cw = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) cu[rg] = D[(HB + fq + 4 * rg) * PQ + HB + fr];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    const double av = ap[kk * 4], na = -av;
+    cu = __builtin_amdgcn_mfma_f64_16x16x4f64(na, av, cu, 0, 0, 0);
+    cw = __builtin_amdgcn_mfma_f64_16x16x4f64(na, bp[kk * 4], cw, 0, 0, 0);
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    D[(HB + fq + 4 * rg) * PQ + HB + fr] = cu[rg];
+    Dt[fr * PQ + HB + fq + 4 * rg] = cw[rg];
   }
 }
 
@@ -164,26 +202,21 @@ __device__ __forceinline__ void potrf128_lds(double *S, double *Dv, int tid, int
           x_c[J] = (I[J][c] - sum_{k<J} L[J][k] x_c[k]) / L[J][J],
        which is the left-looking update of a "row" whose data is row c of the identity. */
     const bool is_row = lane < CB;
-    const int c = lane - CB;
+    double *Dt = Dv + jb * PBLK;                        /* the inverse, TRANSPOSED: Dt[c * PQ + k] = (L^-1)[k][c]; identity on entry */
+    /* this lane's vector: a row of the block, or (lanes >= 32) row c of the identity -- both plain 16-byte LDS reads of
+       colp[0 .. 31], no selects.  The entries right of the diagonal (the symmetric copy of the input) are NOT masked:
+       they only ever flow into entries right of the diagonal of the same row, which nothing reads. */
+    double *colp = is_row ? D + lane * PQ : Dt + (lane - CB) * PQ;
     double a[CB];
-    {
-      /* branch-free: every lane reads a whole row of the block (lanes 32..63 the row of lane - 32, discarded) as 16
-         unconditional ds_read_b128, then selects; a per-entry `k <= lane ? D[..] : 0` compiles to 32 exec-masked
-         branches with a full LDS round trip each (~3k cycles per block, measured as the gap between the column
-         stamps and the block total) */
-      const double *rowp = D + (lane & (CB - 1)) * PQ;
-      double v[CB];
 #pragma unroll
-      for (int k = 0; k < CB; k += 2) { const double2 t = *reinterpret_cast<const double2 *>(rowp + k); v[k] = t.x; v[k + 1] = t.y; }
+    for (int k = 0; k < CB; k += 2) { const double2 t = *reinterpret_cast<const double2 *>(colp + k); a[k] = t.x; a[k + 1] = t.y; }
+    double r0[CB];                                      /* nothing prefetched before the first column of a half */
+    potrf32_step<0, 0>(a, 0.0, a[0], 0.0, 0.0, 0.0, 0.0, D, colp, r0);
+    potrf32_split(D, Dt, lane);
 #pragma unroll
-      for (int k = 0; k < CB; k++) a[k] = is_row ? ((k <= lane) ? v[k] : 0.0) : ((k == c) ? 1.0 : 0.0);
-    }
-    double *colp = is_row ? D + lane * PQ : Dv + jb * PBLK + c;   /* entry J of this lane's vector: colp[J * cstride] */
-    const int cstride = is_row ? 1 : PQ;
-    double r0[CB];                                      /* nothing prefetched before column 0 */
-    potrf32_step<0>(a, 0.0, a[0], 0.0, 0.0, 0.0, 0.0, D, colp, cstride, r0);
-    /* every column was written to D as it was produced (colp); the strict upper triangle of a diagonal
-       block is never read afterwards (TRSM uses Dv, the write-back masks k <= r).
+    for (int k = HB; k < CB; k += 2) { const double2 t = *reinterpret_cast<const double2 *>(colp + k); a[k] = t.x; a[k + 1] = t.y; }
+    potrf32_step<HB, HB>(a, 0.0, a[HB], 0.0, 0.0, 0.0, 0.0, D, colp, r0);
+    /* every column was written to the LDS images as it was produced (colp).
        cholesky.c:120-123: a pivot d <= 0 makes the rsq chain produce NaN (d < 0: rsq = NaN; d = 0: 0 * inf), which
        flows into every later column, so the FIRST row whose diagonal entry is not a positive number is the failing
        column; the caller reports GSL_EDOM and the content of a failed factorisation is unspecified (as in the
@@ -208,13 +241,13 @@ __device__ __forceinline__ void potrf128_lds(double *S, double *Dv, int tid, int
       double *Bb = S + pblk(jb + 1 + (u >> 1), jb);
       const int fi = u & 1;
       const double *ap = Bb + (fi * 16 + (lane & 15)) * PQ + (lane >> 4);
-      const double *bp = Dv + jb * PBLK + (lane & 15) * PQ + (lane >> 4);
+      const double *bp = Dv + jb * PBLK + (lane >> 4) * PQ + (lane & 15);     /* Dinv[n][k] = Dt[k * PQ + n] */
       double4_t x0 = (double4_t){0.0, 0.0, 0.0, 0.0}, x1 = x0;
 #pragma unroll
       for (int kk = 0; kk < 8; kk++) {
         const double av = ap[kk * 4];
-        if (kk < 4) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[kk * 4], x0, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[16 * PQ + kk * 4], x1, 0, 0, 0);
+        if (kk < 4) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[kk * 4 * PQ], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[kk * 4 * PQ + 16], x1, 0, 0, 0);
       }
       frag_store(Bb, fi, 0, lane, x0);
       frag_store(Bb, fi, 1, lane, x1);

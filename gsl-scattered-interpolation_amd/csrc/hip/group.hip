@@ -20,6 +20,7 @@
  * by events -- GSL_SINTERP_NO_RCCL=1 forces that transport for any group.
  */
 #include "common.h"
+#include <new>
 #include <dlfcn.h>
 #include <stdlib.h>
 
@@ -216,6 +217,97 @@ extern "C" int gsl_sinterp_hip_d2h_async(gsl_sinterp_hip_ctx *ctx, void *h_dst, 
   HIP_OK(ctx, hipSetDevice(ctx->device));
   if (!bytes) return ST_SUCCESS;
   HIP_OK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return ST_SUCCESS;
+}
+
+/* Copy pipe of ONE context (round 4): an upload and a download stream beside the context's stream, so that a host batch
+   cut into chunks overlaps  H2D of chunk i+1 | sweep of chunk i | D2H of chunk i-1  (full-duplex PCIe).  upload: the
+   copy runs on the upload stream and everything enqueued on the context's stream AFTERWARDS waits for it; download:
+   the copy runs on the download stream after everything enqueued on the context's stream SO FAR.  Host buffers must be
+   pinned (gsl_sinterp_hip_host_alloc) and stay untouched until gsl_sinterp_hip_pipe_sync. */
+#define PIPE_EVENTS 64
+struct gsl_sinterp_hip_pipe {
+  gsl_sinterp_hip_ctx *ctx;
+  hipStream_t up, down;
+  hipEvent_t ev[PIPE_EVENTS];
+  int n_ev, used;
+};
+
+extern "C" void gsl_sinterp_hip_pipe_destroy(gsl_sinterp_hip_pipe *p)
+{
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  if (p->up) { (void)hipStreamSynchronize(p->up); (void)hipStreamDestroy(p->up); }
+  if (p->down) { (void)hipStreamSynchronize(p->down); (void)hipStreamDestroy(p->down); }
+  for (int i = 0; i < p->n_ev; i++) (void)hipEventDestroy(p->ev[i]);
+  delete p;
+}
+
+extern "C" int gsl_sinterp_hip_pipe_create(gsl_sinterp_hip_ctx *ctx, gsl_sinterp_hip_pipe **out)
+{
+  if (!ctx || !out) return ST_EFAULT;
+  *out = NULL;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  gsl_sinterp_hip_pipe *p = new (std::nothrow) gsl_sinterp_hip_pipe();
+  if (!p) return ST_ENOMEM;
+  p->ctx = ctx; p->up = p->down = NULL; p->n_ev = 0; p->used = 0;
+  if (hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking) != hipSuccess) {
+    gsl_sinterp_hip_pipe_destroy(p);
+    return sinterp_fail(ctx, ST_EFAILED, "pipe: stream", hipSuccess, __FILE__, __LINE__);
+  }
+  *out = p;
+  return ST_SUCCESS;
+}
+
+static int pipe_event(gsl_sinterp_hip_pipe *p, hipEvent_t *ev)
+{
+  gsl_sinterp_hip_ctx *ctx = p->ctx;
+  if (p->used >= PIPE_EVENTS) return sinterp_fail(ctx, ST_EFAILED, "pipe: more than 64 copies between two syncs", hipSuccess, __FILE__, __LINE__);
+  if (p->used >= p->n_ev) { HIP_OK(ctx, hipEventCreateWithFlags(&p->ev[p->n_ev], hipEventDisableTiming)); p->n_ev++; }
+  *ev = p->ev[p->used++];
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_pipe_upload(gsl_sinterp_hip_pipe *p, void *d_dst, const void *h_src, size_t bytes)
+{
+  if (!p) return ST_EFAULT;
+  gsl_sinterp_hip_ctx *ctx = p->ctx;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  if (!bytes) return ST_SUCCESS;
+  hipEvent_t ev;
+  int st = pipe_event(p, &ev);
+  if (st) return st;
+  HIP_OK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, p->up));
+  HIP_OK(ctx, hipEventRecord(ev, p->up));
+  HIP_OK(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_pipe_download(gsl_sinterp_hip_pipe *p, void *h_dst, const void *d_src, size_t bytes)
+{
+  if (!p) return ST_EFAULT;
+  gsl_sinterp_hip_ctx *ctx = p->ctx;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  if (!bytes) return ST_SUCCESS;
+  hipEvent_t ev;
+  int st = pipe_event(p, &ev);
+  if (st) return st;
+  HIP_OK(ctx, hipEventRecord(ev, ctx->stream));
+  HIP_OK(ctx, hipStreamWaitEvent(p->down, ev, 0));
+  HIP_OK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, p->down));
+  return ST_SUCCESS;
+}
+
+extern "C" int gsl_sinterp_hip_pipe_sync(gsl_sinterp_hip_pipe *p)
+{
+  if (!p) return ST_EFAULT;
+  gsl_sinterp_hip_ctx *ctx = p->ctx;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  hipError_t e1 = hipStreamSynchronize(p->up), e2 = hipStreamSynchronize(ctx->stream), e3 = hipStreamSynchronize(p->down);
+  p->used = 0;
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+    return sinterp_fail(ctx, ST_EFAILED, "pipe: synchronize", e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), __FILE__, __LINE__);
   return ST_SUCCESS;
 }
 

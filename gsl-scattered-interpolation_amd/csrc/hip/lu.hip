@@ -524,7 +524,9 @@ static int lu_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, s
   /* measured on MI355X: the single-workgroup block kernel wins while the panel is short
      (<= 1024 rows: its dependent global round trips are few); taller panels go through the
      recursion down to 8-column register-resident panels */
-  if (w <= BW && prow <= (size_t)BT * 2) {
+  /* developer override (tools/time_lu.py): tallest panel the single-workgroup block kernel takes */
+  static const size_t block_rows = getenv("GSL_SINTERP_LU_BLOCK_ROWS") ? (size_t)atol(getenv("GSL_SINTERP_LU_BLOCK_ROWS")) : (size_t)BT * 2;
+  if (w <= BW && prow <= block_rows && prow <= (size_t)BT * 8) {
     if (prow <= (size_t)BT)
       hipLaunchKernelGGL(lu_block_kernel<1>, dim3(1), dim3(BT), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
     else if (prow <= (size_t)BT * 2)
@@ -557,7 +559,7 @@ static int lu_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, s
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }
-  const size_t unit = (prow <= (size_t)BT * 2 && w > BW) ? BW : LB;   /* split on block-kernel boundaries */
+  const size_t unit = (prow <= block_rows && prow <= (size_t)BT * 8 && w > BW) ? BW : LB;   /* split on block-kernel boundaries */
   size_t w1 = ((w / 2 + unit - 1) / unit) * unit;
   if (w1 >= w) w1 = w - unit;
   const size_t w2 = w - w1, c1 = j0 + w1;

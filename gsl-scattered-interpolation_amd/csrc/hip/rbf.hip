@@ -323,6 +323,22 @@ centre_pack_kernel(const double *__restrict__ x, size_t n, size_t xtda, const do
   }
 }
 
+#ifdef SINTERP_DIAG_PROF
+/* developer build only (make prof): pair counters of the culled sweep -- [0] pair-lanes the kernel evaluated (every lane
+   of a wave pays for a centre that ANY of its targets takes), [1] pairs inside the cut-off (the useful ones), [2] centres
+   staged in LDS x targets of the workgroup (what survives the tile culling).  tools/gauss_pairs.py reads them. */
+__device__ unsigned long long g_cull_stats[4];
+extern "C" int gsl_sinterp_hip_debug_cull_stats(unsigned long long *out, int reset)
+{
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cull_stats), sizeof(unsigned long long) * 4);
+  if (e == hipSuccess && reset) { unsigned long long z[4] = {0, 0, 0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_cull_stats), z, sizeof z); }
+  return (int)e;
+}
+#define CULL_STAT(i, v) st_##i += (v)
+#else
+#define CULL_STAT(i, v) do { } while (0)
+#endif
+
 /* KIND = Gaussian: cut-off 2^-72 of the kernel maximum (coef = -eps^2 log2 e); KIND = Wendland: the support
    radius itself (coef = eps), so culling drops terms that are exactly 0 */
 #ifndef CULL_THREADS
@@ -390,6 +406,9 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
   }
   __syncthreads();
 
+#ifdef SINTERP_DIAG_PROF
+  unsigned long long st_0 = 0, st_1 = 0, st_2 = 0;
+#endif
   /* the kept tiles, ascending, CULL_STAGE centres per LDS stage (several small tiles share one pair of barriers) */
   unsigned mi = 0;
   unsigned long long mask = nmask ? s_mask[0] : 0ULL;
@@ -425,7 +444,11 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
           take[tt] = KIND == GSL_SINTERP_RBF_GAUSSIAN ? r2[tt] * coef > -72.0 : r2[tt] * (coef * coef) < 1.0;
           need |= take[tt];
         }
+        CULL_STAT(2, TPT);
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+        CULL_STAT(0, TPT);
+#pragma unroll
+        for (int tt = 0; tt < TPT; tt++) CULL_STAT(1, take[tt] ? 1 : 0);
         /* per-target criterion (see rbf_eval_kernel): a culled tile holds only centres every target of
            the workgroup would reject, so the value is the sum over the centres with term > 2^-72, in
            Morton order -- independent of the workgroup / wave the target landed in */
@@ -440,6 +463,10 @@ rbf_eval_gauss_cull_kernel(double coef, const double *__restrict__ xs, size_t n,
 #pragma unroll
   for (int t = 0; t < TPT; t++)
     if (kidx[t] < m) s[omap ? (size_t)omap[kidx[t]] : kidx[t]] = nan_target<DIM>(yy[t]) ? NAN : acc[t];
+#ifdef SINTERP_DIAG_PROF
+  for (int off = 32; off > 0; off >>= 1) { st_0 += __shfl_xor(st_0, off); st_1 += __shfl_xor(st_1, off); st_2 += __shfl_xor(st_2, off); }
+  if (lane == 0) { atomicAdd(&g_cull_stats[0], st_0); atomicAdd(&g_cull_stats[1], st_1); atomicAdd(&g_cull_stats[2], st_2); }
+#endif
 }
 
 template <int KIND, int TPT>

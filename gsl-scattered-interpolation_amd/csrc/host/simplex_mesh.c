@@ -34,6 +34,7 @@ const int *simplex_mesh_triangles(const simplex_mesh *mesh) { return mesh ? mesh
 const int *simplex_mesh_neighbours(const simplex_mesh *mesh) { return mesh ? mesh->nbr : NULL; }
 const int *simplex_mesh_tree_nodes(const simplex_mesh *mesh) { return mesh ? mesh->node : NULL; }
 void simplex_mesh_set_convex(simplex_mesh *mesh, int convex) { if (mesh) mesh->convex = convex != 0; }
+int simplex_mesh_convex(const simplex_mesh *mesh) { return mesh ? mesh->convex : 0; }
 void simplex_mesh_geometry(const simplex_mesh *mesh, double shift[2], double scale[2])
 {
   for (int j = 0; j < 2; j++) { shift[j] = mesh->shift[j]; scale[j] = mesh->scale[j]; }
@@ -100,6 +101,53 @@ static int derive_neighbours(simplex_mesh *m)
   return status;
 }
 
+/* Convexity of an imported mesh, decided from its boundary (the edges without a neighbour): convex = ONE closed loop
+   whose turns all have the sign of the loop's orientation (collinear boundary points allowed).  A hole, a concave
+   outline, several components or a non-manifold boundary vertex all answer 0, and the locate step then never takes a
+   boundary edge in the walking direction as proof that the target lies outside (exhaustive scan instead). */
+static int mesh_detect_convex(const simplex_mesh *m)
+{
+  const size_t np = m->n_points, nt = m->n_tri;
+  int *next = (int *)malloc(np * sizeof(int));
+  if (!next) return 0;
+  for (size_t i = 0; i < np; i++) next[i] = -1;
+  size_t n_edges = 0;
+  int first = -1, ok = 1;
+  for (size_t t = 0; t < nt && ok; t++) {
+    const int *v = m->tri + 3 * t;
+    const double *p0 = m->points + 2 * v[0], *p1 = m->points + 2 * v[1], *p2 = m->points + 2 * v[2];
+    const double orient = (p1[0] - p0[0]) * (p2[1] - p0[1]) - (p1[1] - p0[1]) * (p2[0] - p0[0]);
+    for (int k = 0; k < 3; k++) {
+      if (m->nbr[3 * t + k] >= 0) continue;
+      int a = v[(k + 1) % 3], b = v[(k + 2) % 3];               /* the edge opposite vertex k, in the triangle's order */
+      if (orient < 0) { const int tmp = a; a = b; b = tmp; }    /* walk every boundary edge counter-clockwise */
+      if (next[a] >= 0) { ok = 0; break; }                      /* two boundary edges leave one vertex: not a simple loop */
+      next[a] = b;
+      if (first < 0) first = a;
+      n_edges++;
+    }
+  }
+  if (ok && (first < 0 || n_edges < 3)) ok = 0;
+  if (ok) {
+    size_t seen = 0;
+    int a = first;
+    do {
+      const int b = next[a];
+      if (b < 0 || next[b] < 0) { ok = 0; break; }
+      const int c = next[b];
+      const double *pa = m->points + 2 * a, *pb = m->points + 2 * b, *pc = m->points + 2 * c;
+      const double ux = pb[0] - pa[0], uy = pb[1] - pa[1], wx = pc[0] - pb[0], wy = pc[1] - pb[1];
+      const double cross = ux * wy - uy * wx, tol = 1e-12 * sqrt((ux * ux + uy * uy) * (wx * wx + wy * wy));
+      if (cross < -tol) { ok = 0; break; }                      /* a right turn on a counter-clockwise loop: concave */
+      a = b;
+      seen++;
+    } while (a != first && seen <= n_edges);
+    if (ok && (a != first || seen != n_edges)) ok = 0;          /* more boundary edges than this loop: holes / components */
+  }
+  free(next);
+  return ok;
+}
+
 simplex_mesh *simplex_mesh_import(const gsl_matrix *points, const int *triangles, const int *neighbours, size_t n_triangles)
 {
   if (!points || !triangles) GSL_ERROR_NULL("simplex_mesh_import: null argument", GSL_EFAULT);
@@ -145,6 +193,7 @@ simplex_mesh *simplex_mesh_import(const gsl_matrix *points, const int *triangles
     const int st = derive_neighbours(m);
     if (st != GSL_SUCCESS) { simplex_mesh_free(m); GSL_ERROR_NULL("simplex_mesh_import: cannot derive neighbour links", st); }
   }
+  m->convex = mesh_detect_convex(m);                    /* simplex_mesh_set_convex overrides */
   return m;
 }
 

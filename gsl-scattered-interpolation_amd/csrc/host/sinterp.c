@@ -156,6 +156,93 @@ static int shard_eval_many(shard_set *ss, size_t dim, const gsl_matrix *y, gsl_v
 }
 
 /* ======================================================================== */
+/* host batches on ONE device: chunks pipelined over the copy pipe            */
+/* ======================================================================== */
+/* The facade's host-matrix entries (gsl_sinterp_eval_many, simplex_tree_device_eval_many) used to run
+   repack -> hipMalloc -> H2D -> sweep -> D2H -> copy-out strictly in sequence, with pageable staging allocated per call.
+   Here a batch is cut into chunks; chunk i is repacked into pinned staging and its H2D -> sweep -> D2H chain enqueued on
+   the context's copy pipe (upload stream | context stream | download stream) while the host already repacks chunk i+1,
+   so the PCIe directions and the sweep overlap and the per-call allocations are gone (grow-only buffers in the state).
+   Results are bit-identical to the one-shot path: a value depends on (model, target) only. */
+#define CHUNK_MIN ((size_t)1 << 19)      /* keeps every chunk on the large-batch kernels (two-level reorder from 2^18 targets) */
+#define CHUNK_MAX_N 8
+typedef struct {
+  gsl_sinterp_hip_pipe *pipe;
+  void *h_stage;                        /* pinned: targets | values | leaf */
+  size_t h_bytes;
+  double *d_y, *d_s;
+  int *d_leaf;
+  size_t cap;                           /* targets the device buffers hold (any dim <= 3) */
+} chunk_set;
+
+typedef int (*chunk_eval_fn)(void *state, const double *d_y, size_t m, double *d_s, int *d_leaf);
+
+static void chunk_set_release(chunk_set *cs, gsl_sinterp_hip_ctx *c)
+{
+  if (cs->pipe) gsl_sinterp_hip_pipe_destroy(cs->pipe);
+  cs->pipe = NULL;
+  if (c) { gsl_sinterp_hip_free(c, cs->d_y); gsl_sinterp_hip_free(c, cs->d_s); gsl_sinterp_hip_free(c, cs->d_leaf); }
+  cs->d_y = cs->d_s = NULL; cs->d_leaf = NULL; cs->cap = 0;
+  gsl_sinterp_hip_host_free(cs->h_stage);
+  cs->h_stage = NULL; cs->h_bytes = 0;
+}
+
+static int chunk_eval_many(chunk_set *cs, gsl_sinterp_hip_ctx *c, size_t dim, const gsl_matrix *y, gsl_vector *sv, int *leaf,
+                           chunk_eval_fn fn, void *state, int want_leaf, size_t *n_neg)
+{
+  const size_t m = y->size1;
+  if (n_neg) *n_neg = 0;
+  if (m == 0) return GSL_SUCCESS;
+  int st = GSL_SUCCESS;
+  if (!cs->pipe) st = gsl_sinterp_hip_pipe_create(c, &cs->pipe);
+  const size_t o_s = m * dim * sizeof(double), o_l = o_s + m * sizeof(double), need = o_l + (want_leaf ? m * sizeof(int) : 0);
+  if (!st && need > cs->h_bytes) {
+    gsl_sinterp_hip_host_free(cs->h_stage);
+    cs->h_stage = NULL; cs->h_bytes = 0;
+    st = gsl_sinterp_hip_host_alloc(&cs->h_stage, need);
+    if (!st) cs->h_bytes = need;
+  }
+  if (!st && m > cs->cap) {
+    gsl_sinterp_hip_free(c, cs->d_y); gsl_sinterp_hip_free(c, cs->d_s); gsl_sinterp_hip_free(c, cs->d_leaf);
+    cs->d_y = cs->d_s = NULL; cs->d_leaf = NULL; cs->cap = 0;
+    st = gsl_sinterp_hip_malloc(c, (void **)&cs->d_y, m * 3 * sizeof(double));
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&cs->d_s, m * sizeof(double));
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&cs->d_leaf, m * sizeof(int));
+    if (!st) cs->cap = m;
+  }
+  if (st) { gsl_error(gsl_sinterp_hip_last_error(c), __FILE__, __LINE__, st); return st; }
+  double *h_y = (double *)cs->h_stage, *h_s = (double *)((char *)cs->h_stage + o_s);
+  int *h_l = want_leaf ? (int *)((char *)cs->h_stage + o_l) : NULL;
+  size_t nch = m / CHUNK_MIN;
+  if (nch < 1) nch = 1;
+  if (nch > CHUNK_MAX_N) nch = CHUNK_MAX_N;
+  const int packed = y->tda == dim;
+  for (size_t ch = 0; ch < nch && !st; ch++) {
+    size_t first, cnt;
+    gsl_sinterp_hip_shard_bounds(m, (int)nch, (int)ch, &first, &cnt);
+    if (!cnt) continue;
+    if (packed) memcpy(h_y + first * dim, y->data + first * dim, cnt * dim * sizeof(double));
+    else
+      for (size_t k = first; k < first + cnt; k++)
+        for (size_t cc = 0; cc < dim; cc++) h_y[k * dim + cc] = y->data[k * y->tda + cc];
+    st = gsl_sinterp_hip_pipe_upload(cs->pipe, cs->d_y + first * dim, h_y + first * dim, cnt * dim * sizeof(double));
+    if (!st) st = fn(state, cs->d_y + first * dim, cnt, cs->d_s + first, want_leaf ? cs->d_leaf + first : NULL);
+    if (!st) st = gsl_sinterp_hip_pipe_download(cs->pipe, h_s + first, cs->d_s + first, cnt * sizeof(double));
+    if (!st && want_leaf) st = gsl_sinterp_hip_pipe_download(cs->pipe, h_l + first, cs->d_leaf + first, cnt * sizeof(int));
+  }
+  int s2 = gsl_sinterp_hip_pipe_sync(cs->pipe);            /* always drain, also after a failure */
+  if (!st) st = s2;
+  if (st) { gsl_error(gsl_sinterp_hip_last_error(c), __FILE__, __LINE__, st); return st; }
+  if (sv->stride == 1) memcpy(sv->data, h_s, m * sizeof(double));
+  else for (size_t k = 0; k < m; k++) sv->data[k * sv->stride] = h_s[k];
+  size_t neg = 0;
+  if (want_leaf)
+    for (size_t k = 0; k < m; k++) { neg += h_l[k] < 0; if (leaf) leaf[k] = h_l[k]; }
+  if (n_neg) *n_neg = neg;
+  return GSL_SUCCESS;
+}
+
+/* ======================================================================== */
 /* simplex_tree_device                                                       */
 /* ======================================================================== */
 struct simplex_tree_device {
@@ -171,6 +258,7 @@ struct simplex_tree_device {
   shard_set ss;
   void *m_records[SINTERP_MAX_DEVICES], *m_leaftab[SINTERP_MAX_DEVICES];
   int *m_pidx[SINTERP_MAX_DEVICES];
+  chunk_set cs;                    /* single-device mirror: pipelined host batches */
 };
 
 gsl_sinterp_hip_ctx *simplex_tree_device_ctx(simplex_tree_device *dev) { return dev ? dev->ctx : NULL; }
@@ -188,6 +276,7 @@ void simplex_tree_device_free(simplex_tree_device *dev)
     return;
   }
   if (dev->ctx) {
+    chunk_set_release(&dev->cs, dev->ctx);
     gsl_sinterp_hip_free(dev->ctx, dev->d_records);
     gsl_sinterp_hip_free(dev->ctx, dev->d_leaftab);
     gsl_sinterp_hip_free(dev->ctx, dev->d_pidx);
@@ -412,6 +501,13 @@ int simplex_tree_device_eval_resident(simplex_tree_device *dev, const double *d_
   return GSL_SUCCESS;
 }
 
+static int simplex_chunk_eval(void *state, const double *d_y, size_t m, double *d_s, int *d_leaf)
+{
+  simplex_tree_device *dev = (simplex_tree_device *)state;
+  return gsl_sinterp_hip_bary_eval(dev->ctx, dev->n_nodes, dev->d_records, dev->d_leaftab, dev->scale, d_y, m, 2, d_s, d_leaf,
+                                   (long long *)NULL);     /* NULL: no host read-back, the call stays asynchronous */
+}
+
 int simplex_tree_device_eval_many(simplex_tree_device *dev, const gsl_matrix *targets,
                                   gsl_vector *values, simplex_index *leaf)
 {
@@ -430,31 +526,12 @@ int simplex_tree_device_eval_many(simplex_tree_device *dev, const gsl_matrix *ta
     return GSL_SUCCESS;
   }
 
-  gsl_sinterp_hip_ctx *c = dev->ctx;
-  double *h_y = (double *)malloc(m * 2 * sizeof(double));
-  double *h_s = (double *)malloc(m * sizeof(double));
-  if (!h_y || !h_s) { free(h_y); free(h_s); GSL_ERROR("simplex_tree_device_eval_many: out of memory", GSL_ENOMEM); }
-  for (size_t k = 0; k < m; k++) {
-    h_y[2 * k] = targets->data[k * targets->tda];
-    h_y[2 * k + 1] = targets->data[k * targets->tda + 1];
-  }
-  double *d_y = NULL, *d_s = NULL;
-  int *d_leaf = NULL;
-  long long outside = 0;
-  int st = gsl_sinterp_hip_malloc(c, (void **)&d_y, m * 2 * sizeof(double));
-  if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_s, m * sizeof(double));
-  if (!st && leaf) st = gsl_sinterp_hip_malloc(c, (void **)&d_leaf, m * sizeof(int));
-  if (!st) st = gsl_sinterp_hip_h2d(c, d_y, h_y, m * 2 * sizeof(double));
-  if (!st) st = gsl_sinterp_hip_bary_eval(c, dev->n_nodes, dev->d_records, dev->d_leaftab, dev->scale,
-                                          d_y, m, 2, d_s, d_leaf, &outside);
-  int eval_st = st;
-  if (st == GSL_EDOM) st = GSL_SUCCESS;
-  if (!st) st = gsl_sinterp_hip_d2h(c, h_s, d_s, m * sizeof(double));
-  if (!st && leaf) st = gsl_sinterp_hip_d2h(c, leaf, d_leaf, m * sizeof(int));
-  if (!st) for (size_t k = 0; k < m; k++) gsl_vector_set(values, k, h_s[k]);
-  gsl_sinterp_hip_free(c, d_y); gsl_sinterp_hip_free(c, d_s); gsl_sinterp_hip_free(c, d_leaf);
-  free(h_y); free(h_s);
-  HIP_TRY(st, c);
+  /* single device: chunks over the copy pipe (H2D | sweep | D2H overlap); the leaf indices always come back, they
+     carry the outside-the-cage verdict (index -1, value NaN) */
+  size_t outside_n = 0;
+  int st = chunk_eval_many(&dev->cs, dev->ctx, 2, targets, values, leaf, &simplex_chunk_eval, dev, 1, &outside_n);
+  if (st != GSL_SUCCESS) GSL_ERROR("simplex_tree_device_eval_many: evaluation failed", st);
+  const int eval_st = outside_n ? GSL_EDOM : GSL_SUCCESS;
   if (eval_st == GSL_EDOM) GSL_ERROR("simplex_tree_device_eval_many: target(s) outside the caging simplex", GSL_EDOM);
   return GSL_SUCCESS;
 }
@@ -533,6 +610,7 @@ typedef struct {
   /* thin-plate spline with its affine tail (gsl_sinterp_rbf_tps_affine): c_0 + sum_a c_a y_a added by every sweep */
   int affine;
   double poly[4];
+  chunk_set cs;                /* single-device: pipelined host batches */
 } rbf_state;
 
 static unsigned long long next_model_id(void)
@@ -573,6 +651,7 @@ static void rbf_release_devices(rbf_state *st)
     }
     shard_set_release(&st->ss);
   } else if (st->ctx) {
+    chunk_set_release(&st->cs, st->ctx);
     gsl_sinterp_hip_free(st->ctx, st->d_x);       /* one buffer: d_w points into it */
     gsl_sinterp_hip_ctx_destroy(st->ctx);
   }
@@ -710,6 +789,13 @@ static int rbf_shard_eval(void *state, int member, const double *d_y, size_t m, 
   return rbf_sweep(st, gsl_sinterp_hip_group_ctx(st->ss.grp, member), model, model + st->n * st->dim, d_y, m, st->dim, d_s);
 }
 
+static int rbf_chunk_eval(void *state, const double *d_y, size_t m, double *d_s, int *d_leaf)
+{
+  (void)d_leaf;
+  const rbf_state *st = (const rbf_state *)state;
+  return rbf_sweep(st, st->ctx, st->d_x, st->d_w, d_y, m, st->dim, d_s);
+}
+
 static int rbf_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vector *sv, int *leaf)
 {
   const rbf_state *st = (const rbf_state *)interp->state;
@@ -723,23 +809,12 @@ static int rbf_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vec
     if (leaf) for (size_t k = 0; k < m; k++) leaf[k] = -1;
     return GSL_SUCCESS;
   }
-  gsl_sinterp_hip_ctx *c = st->ctx;
-  double *h_y = (double *)malloc(m * dim * sizeof(double));
-  double *h_s = (double *)malloc(m * sizeof(double));
-  if (!h_y || !h_s) { free(h_y); free(h_s); GSL_ERROR("gsl_sinterp_eval_many: out of memory", GSL_ENOMEM); }
-  for (size_t k = 0; k < m; k++)
-    for (size_t cdim = 0; cdim < dim; cdim++) h_y[k * dim + cdim] = y->data[k * y->tda + cdim];
-  double *d_y = NULL, *d_s = NULL;
-  int s = gsl_sinterp_hip_malloc(c, (void **)&d_y, m * dim * sizeof(double));
-  if (!s) s = gsl_sinterp_hip_malloc(c, (void **)&d_s, m * sizeof(double));
-  if (!s) s = gsl_sinterp_hip_h2d(c, d_y, h_y, m * dim * sizeof(double));
-  if (!s) s = rbf_sweep(st, c, st->d_x, st->d_w, d_y, m, dim, d_s);
-  if (!s) s = gsl_sinterp_hip_d2h(c, h_s, d_s, m * sizeof(double));
-  if (!s) for (size_t k = 0; k < m; k++) gsl_vector_set(sv, k, h_s[k]);
-  if (!s && leaf) for (size_t k = 0; k < m; k++) leaf[k] = -1;
-  gsl_sinterp_hip_free(c, d_y); gsl_sinterp_hip_free(c, d_s);
-  free(h_y); free(h_s);
-  HIP_TRY(s, c);
+  {
+    rbf_state *mst = (rbf_state *)interp->state;           /* staging buffers are grow-only caches inside the state */
+    int s = chunk_eval_many(&mst->cs, st->ctx, dim, y, sv, NULL, &rbf_chunk_eval, mst, 0, NULL);
+    if (s != GSL_SUCCESS) GSL_ERROR("gsl_sinterp_eval_many: evaluation failed", s);
+    if (leaf) for (size_t k = 0; k < m; k++) leaf[k] = -1;
+  }
   return GSL_SUCCESS;
 }
 

@@ -213,8 +213,12 @@ const int *simplex_mesh_triangles(const simplex_mesh *mesh);   /* [3 n] */
 const int *simplex_mesh_neighbours(const simplex_mesh *mesh);  /* [3 n] */
 const int *simplex_mesh_tree_nodes(const simplex_mesh *mesh);  /* [n] DAG node of every triangle (from_tree), else NULL */
 void simplex_mesh_geometry(const simplex_mesh *mesh, double shift[2], double scale[2]);
-/* 0: walks that run into a hull edge are resolved by an exhaustive scan (meshes with holes / concave outlines) */
+/* convex = 1: a boundary edge in the walking direction proves the target outside (index -1, NaN, GSL_EDOM); 0: such walks
+   are resolved by an exhaustive scan (meshes with holes / concave outlines).  simplex_mesh_import decides it from the
+   boundary (one closed loop without a reflex turn = convex), simplex_mesh_from_tree exports convex = 1 (the hull of a
+   Delaunay triangulation); simplex_mesh_set_convex overrides, simplex_mesh_convex reads the current setting. */
 void simplex_mesh_set_convex(simplex_mesh *mesh, int convex);
+int simplex_mesh_convex(const simplex_mesh *mesh);
 simplex_mesh_device *simplex_mesh_device_alloc(const simplex_mesh *mesh, int device);
 void simplex_mesh_device_free(simplex_mesh_device *dev);
 int simplex_mesh_device_set_response(simplex_mesh_device *dev, const gsl_vector *response);

@@ -87,6 +87,16 @@ int gsl_sinterp_hip_h2d_async(gsl_sinterp_hip_ctx *ctx, void *d_dst, const void 
 int gsl_sinterp_hip_d2h_async(gsl_sinterp_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int gsl_sinterp_hip_host_alloc(void **h_ptr, size_t bytes);
 void gsl_sinterp_hip_host_free(void *h_ptr);
+/* copy pipe of one context: an upload and a download stream beside the context's stream, so that the chunks of a host
+   batch overlap H2D | sweep | D2H.  upload: later work on the context's stream waits for the copy; download: the copy
+   waits for the work enqueued on the context's stream so far.  Pinned host buffers, untouched until pipe_sync (which
+   also synchronises the context's stream).  At most 64 copies between two syncs. */
+typedef struct gsl_sinterp_hip_pipe gsl_sinterp_hip_pipe;
+int gsl_sinterp_hip_pipe_create(gsl_sinterp_hip_ctx *ctx, gsl_sinterp_hip_pipe **out);
+void gsl_sinterp_hip_pipe_destroy(gsl_sinterp_hip_pipe *pipe);
+int gsl_sinterp_hip_pipe_upload(gsl_sinterp_hip_pipe *pipe, void *d_dst, const void *h_src, size_t bytes);
+int gsl_sinterp_hip_pipe_download(gsl_sinterp_hip_pipe *pipe, void *h_dst, const void *d_src, size_t bytes);
+int gsl_sinterp_hip_pipe_sync(gsl_sinterp_hip_pipe *pipe);
 
 /* ---- barycentric evaluation over a host-built Delaunay history DAG ------- */
 /* One 64-byte record per DAG node (see DESIGN.md "HBM layout"). */
@@ -188,7 +198,11 @@ int gsl_sinterp_hip_rbf_eval(gsl_sinterp_hip_ctx *ctx, int kind, double eps, con
    every init): the Gaussian / Wendland sweep's per-model preprocessing -- Morton cell sort of the centres, packed
    {x, w} records, tile boxes -- is then done once per (model_id, d_x, d_w, n, dim, kind) and reused by later calls
    on this context (the single-point call behind gsl_sinterp_eval_e pays 1 launch instead of 9).  model_id = 0 is
-   gsl_sinterp_hip_rbf_eval: nothing is assumed about the buffers, nothing cached.  Same bits either way. */
+   gsl_sinterp_hip_rbf_eval: nothing is assumed about the buffers, nothing cached.  Same bits either way.
+   CONTRACT: the id vouches for the CONTENT of d_x / d_w, not just their addresses -- whoever rewrites either buffer (a
+   new init into the same allocation, a checkpoint load, a broadcast) must pass a fresh id afterwards; reusing an id
+   across re-filled buffers evaluates the OLD centres / weights silently.  The facade draws a new id in every init and
+   fread (csrc/host/sinterp.c: next_model_id); ids are compared per context, so two contexts may use the same values. */
 int gsl_sinterp_hip_rbf_eval_model(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x,
                                    size_t n, int dim, size_t xtda, const double *d_w,
                                    const double *d_y, size_t m, size_t ytda, double *d_s, unsigned long long model_id);

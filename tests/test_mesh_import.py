@@ -22,6 +22,34 @@ def test_import_derives_qhull_neighbours(pkg, orc):
     assert np.array_equal(derived.triangles(), tri) and derived.tree_nodes() is None
 
 
+def test_import_decides_convexity_from_the_boundary(pkg, orc):
+    """an imported mesh used to default to convex = 1, so targets inside a mesh with a hole or a concave
+    outline were reported outside unless the caller knew to call simplex_mesh_set_convex(mesh, 0).  The import now looks
+    at the boundary loop: QHull's Delaunay output is convex; a punched hole, an L-shaped outline and two separate
+    components are not."""
+    x = orc.synth_centres(800, 2)
+    d, tri, nbr = qhull(x)
+    assert pkg.SimplexMesh.from_arrays(x, tri, nbr).convex() and pkg.SimplexMesh.from_arrays(x, tri).convex()
+    cen = x[tri].mean(axis=1)
+    hole = ~((np.abs(cen[:, 0] - 0.5) < 0.2) & (np.abs(cen[:, 1] - 0.5) < 0.2))
+    assert not pkg.SimplexMesh.from_arrays(x, np.ascontiguousarray(tri[hole])).convex()
+    ell = ~((cen[:, 0] > 0.5) & (cen[:, 1] > 0.5))                                     # L-shaped outline
+    assert not pkg.SimplexMesh.from_arrays(x, np.ascontiguousarray(tri[ell])).convex()
+    two = (cen[:, 0] < 0.3) | (cen[:, 0] > 0.7)                                        # two components
+    assert not pkg.SimplexMesh.from_arrays(x, np.ascontiguousarray(tri[two])).convex()
+    m = pkg.SimplexMesh.from_arrays(x, tri)
+    m.set_convex(False)
+    assert not m.convex()
+    # a grid triangulation: collinear boundary points are not reflex turns
+    g = np.array([[i, j] for i in range(5) for j in range(5)], dtype=np.float64)
+    gt = []
+    for i in range(4):
+        for j in range(4):
+            a, b, c, e = 5 * i + j, 5 * i + j + 1, 5 * (i + 1) + j, 5 * (i + 1) + j + 1
+            gt += [[a, c, b], [b, c, e]]
+    assert pkg.SimplexMesh.from_arrays(g, np.array(gt, dtype=np.int32)).convex()
+
+
 def test_import_rejects_bad_arrays(pkg, orc):
     x = orc.synth_centres(50, 2)
     _, tri, nbr = qhull(x)
