@@ -339,11 +339,71 @@ def main():
         out["extra"] = dict(head["extra"], other_configs=others)
         if env.rehearsal:
             out["extra"]["REHEARSAL"] = "ranks share one GPU / non-RCCL backend: control-flow check only, the numbers are meaningless"
+        if world == 1 and not args.only:
+            try:
+                out["facade_host_mpts"] = {k: facade_host_path(env, k) for k in ("C4", "C5")}
+            except Exception as exc:                      # never let the side measurement take the line down
+                out["facade_host_mpts"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(CONFIGS[headline], head["n_centres"], head["dim"], head["targets_total"])
         print(json.dumps(out))
     if env.world > 1:
         env.dist.destroy_process_group()
+
+
+def facade_host_path(env, name, reps=3):
+    """The drop-in entries fed with HOST matrices (gsl_sinterp_eval_many / simplex_tree_device_eval_many): chunks of the
+    batch pipelined over the copy pipe (H2D | sweep | D2H).  Reported beside the PCIe bound measured in this run
+    (hipMemcpy of the same pageable arrays, both directions one after the other) -- never `value`."""
+    import numpy as np
+    torch, pkg, ctx = env.torch, env.pkg, env.ctx
+    cfg = CONFIGS[name]
+    dim, n, m = cfg["dim"], cfg["n"], cfg["m"]
+    d_x = torch.empty((n, dim), dtype=torch.float64, device="cuda")
+    d_y = torch.empty((m, dim), dtype=torch.float64, device="cuda")
+    ctx.synth_unit(0xC0FFEE01, 0, 0.0, 1.0, d_x.data_ptr(), n * dim)
+    ctx.synth_unit(0xC0FFEE02, 0, 0.02, 0.96, d_y.data_ptr(), m * dim)
+    x = d_x.cpu().numpy()
+    y = d_y.cpu().numpy()
+    f = np.sin(3.0 * x[:, 0]) + np.sin(6.0 * x[:, 1]) + (np.sin(9.0 * x[:, 2]) if dim == 3 else 0.0)
+    vals = np.zeros(m)
+    leaf = np.zeros(m, dtype=np.int32)
+    if cfg["kind"] == "bary":
+        tree = pkg.SimplexTree(2, n)
+        assert tree.init(x, flags=0, rng=pkg.capi.Rng(0)) == 0
+        dev = tree.device_alloc(0)
+        assert dev.set_response(f) == 0
+        run = lambda: dev.eval_many(y, out=(vals, leaf))[0]
+        bytes_up, bytes_down = 16.0 * m, 12.0 * m
+    else:
+        s = pkg.Sinterp("gaussian", dim, n, 0)
+        assert s.init(x, f) == 0
+        run = lambda: s.eval_many(y, out=vals)[0]
+        bytes_up, bytes_down = 8.0 * dim * m, 8.0 * m
+    assert run() == 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        assert run() == 0
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    # the PCIe bound of the same pageable arrays: plain copies, one direction after the other
+    d_v = torch.empty(m, dtype=torch.float64, device="cuda")
+    ty, tv = torch.from_numpy(y), torch.from_numpy(vals)
+    tl = torch.from_numpy(leaf)
+    d_l = torch.empty(m, dtype=torch.int32, device="cuda")
+    d_y.copy_(ty); tv.copy_(d_v); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        d_y.copy_(ty)
+        tv.copy_(d_v)
+        if cfg["kind"] == "bary":
+            tl.copy_(d_l)
+        torch.cuda.synchronize()
+    ms_pcie = (time.perf_counter() - t0) / reps * 1e3
+    return {"config": name, "ms_per_batch": round(ms, 3), "mpts": round(m / ms / 1e3, 2), "bytes_per_target": (bytes_up + bytes_down) / m,
+            "pcie_copy_ms_same_arrays": round(ms_pcie, 3), "pcie_bound_mpts": round(m / ms_pcie / 1e3, 2),
+            "frac_of_pcie_bound": round(ms_pcie / ms, 4),
+            "note": "host gsl_matrix in, host gsl_vector out through the C facade (pageable memory, dense rows); the bound is "
+                    "torch's H2D + D2H of the same arrays, serial, measured in this run"}
 
 
 def time_top_gemm(ctx, n, reps=3):

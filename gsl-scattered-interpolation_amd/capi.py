@@ -634,10 +634,11 @@ class DeviceTree:
     def set_response(self, response):
         return lib().simplex_tree_device_set_response(self._h, C.byref(as_vector(response)))
 
-    def eval_many(self, targets, want_leaf=True):
+    def eval_many(self, targets, want_leaf=True, out=None):
+        """out = (values, leaf) preallocated arrays (timing loops: fresh arrays pay first-touch page faults in the copy)"""
         m = targets.shape[0]
-        vals = np.empty(m, dtype=np.float64)
-        leaf = np.empty(m, dtype=np.int32) if want_leaf else None
+        vals = np.empty(m, dtype=np.float64) if out is None else out[0]
+        leaf = (np.empty(m, dtype=np.int32) if out is None else out[1]) if want_leaf else None
         st = lib().simplex_tree_device_eval_many(self._h, C.byref(as_matrix(targets)), C.byref(as_vector(vals)),
                                                  leaf.ctypes.data_as(_pi) if want_leaf else None)
         return st, vals, leaf
@@ -837,9 +838,9 @@ class Sinterp:
                                       C.byref(out))
         return st, out.value
 
-    def eval_many(self, y, want_leaf=False):
+    def eval_many(self, y, want_leaf=False, out=None):
         m = y.shape[0]
-        s = np.empty(m, dtype=np.float64)
+        s = np.empty(m, dtype=np.float64) if out is None else out
         leaf = np.empty(m, dtype=np.int32) if want_leaf else None
         st = lib().gsl_sinterp_eval_many(self._p, C.byref(as_matrix(y)), C.byref(as_vector(s)),
                                          leaf.ctypes.data_as(_pi) if want_leaf else None)

@@ -284,17 +284,30 @@ extern "C" int gsl_sinterp_hip_pipe_upload(gsl_sinterp_hip_pipe *p, void *d_dst,
   return ST_SUCCESS;
 }
 
-extern "C" int gsl_sinterp_hip_pipe_download(gsl_sinterp_hip_pipe *p, void *h_dst, const void *d_src, size_t bytes)
+/* mark: remember "everything enqueued on the context's stream so far" (an event); *mark >= 0 on success */
+extern "C" int gsl_sinterp_hip_pipe_mark(gsl_sinterp_hip_pipe *p, int *mark)
+{
+  if (!p || !mark) return ST_EFAULT;
+  gsl_sinterp_hip_ctx *ctx = p->ctx;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  hipEvent_t ev;
+  int st = pipe_event(p, &ev);
+  if (st) return st;
+  HIP_OK(ctx, hipEventRecord(ev, ctx->stream));
+  *mark = p->used - 1;
+  return ST_SUCCESS;
+}
+
+/* mark < 0: behind everything enqueued on the context's stream so far; else behind that mark only */
+extern "C" int gsl_sinterp_hip_pipe_download(gsl_sinterp_hip_pipe *p, int mark, void *h_dst, const void *d_src, size_t bytes)
 {
   if (!p) return ST_EFAULT;
   gsl_sinterp_hip_ctx *ctx = p->ctx;
   HIP_OK(ctx, hipSetDevice(ctx->device));
   if (!bytes) return ST_SUCCESS;
-  hipEvent_t ev;
-  int st = pipe_event(p, &ev);
-  if (st) return st;
-  HIP_OK(ctx, hipEventRecord(ev, ctx->stream));
-  HIP_OK(ctx, hipStreamWaitEvent(p->down, ev, 0));
+  if (mark < 0) { int st = gsl_sinterp_hip_pipe_mark(p, &mark); if (st) return st; }
+  if (mark >= p->used) return sinterp_fail(ctx, ST_EINVAL, "pipe: stale mark", hipSuccess, __FILE__, __LINE__);
+  HIP_OK(ctx, hipStreamWaitEvent(p->down, p->ev[mark], 0));
   HIP_OK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, p->down));
   return ST_SUCCESS;
 }
@@ -308,6 +321,37 @@ extern "C" int gsl_sinterp_hip_pipe_sync(gsl_sinterp_hip_pipe *p)
   p->used = 0;
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
     return sinterp_fail(ctx, ST_EFAILED, "pipe: synchronize", e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), __FILE__, __LINE__);
+  return ST_SUCCESS;
+}
+
+/* number of negative entries of d_v[0 .. m) (leaf / triangle indices: -1 = outside) -- one 8-byte read-back instead of a
+   host pass over m indices; synchronises the context's stream */
+__global__ void __launch_bounds__(256)
+count_negative_kernel(const int *__restrict__ v, size_t m, unsigned long long *__restrict__ out)
+{
+  unsigned long long c = 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) c += v[k] < 0;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+extern "C" int gsl_sinterp_hip_count_negative(gsl_sinterp_hip_ctx *ctx, const int *d_v, size_t m, long long *h_count)
+{
+  REQUIRE(ctx, ctx != NULL && h_count != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  *h_count = 0;
+  if (!m) return ST_SUCCESS;
+  unsigned long long *d_c = (unsigned long long *)((char *)ctx->d_scratch + 512);
+  HIP_OK(ctx, hipMemsetAsync(d_c, 0, sizeof(unsigned long long), ctx->stream));
+  size_t blocks = (m + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(count_negative_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_v, m, d_c);
+  LAUNCH_CHECK(ctx);
+  unsigned long long h = 0;
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(&h, d_c, sizeof h, hipMemcpyDeviceToHost));
+  *h_count = (long long)h;
   return ST_SUCCESS;
 }
 

@@ -89,14 +89,17 @@ int gsl_sinterp_hip_host_alloc(void **h_ptr, size_t bytes);
 void gsl_sinterp_hip_host_free(void *h_ptr);
 /* copy pipe of one context: an upload and a download stream beside the context's stream, so that the chunks of a host
    batch overlap H2D | sweep | D2H.  upload: later work on the context's stream waits for the copy; download: the copy
-   waits for the work enqueued on the context's stream so far.  Pinned host buffers, untouched until pipe_sync (which
+   waits for the work enqueued on the context's stream up to a mark (or so far).  Pinned host buffers, untouched until pipe_sync (which
    also synchronises the context's stream).  At most 64 copies between two syncs. */
 typedef struct gsl_sinterp_hip_pipe gsl_sinterp_hip_pipe;
 int gsl_sinterp_hip_pipe_create(gsl_sinterp_hip_ctx *ctx, gsl_sinterp_hip_pipe **out);
 void gsl_sinterp_hip_pipe_destroy(gsl_sinterp_hip_pipe *pipe);
 int gsl_sinterp_hip_pipe_upload(gsl_sinterp_hip_pipe *pipe, void *d_dst, const void *h_src, size_t bytes);
-int gsl_sinterp_hip_pipe_download(gsl_sinterp_hip_pipe *pipe, void *h_dst, const void *d_src, size_t bytes);
+int gsl_sinterp_hip_pipe_mark(gsl_sinterp_hip_pipe *pipe, int *mark);      /* "the context's stream up to here" */
+int gsl_sinterp_hip_pipe_download(gsl_sinterp_hip_pipe *pipe, int mark, void *h_dst, const void *d_src, size_t bytes);   /* mark < 0: now */
 int gsl_sinterp_hip_pipe_sync(gsl_sinterp_hip_pipe *pipe);
+/* number of negative entries of d_v[0 .. m) (-1 = outside the cage / mesh); synchronises the context's stream */
+int gsl_sinterp_hip_count_negative(gsl_sinterp_hip_ctx *ctx, const int *d_v, size_t m, long long *h_count);
 
 /* ---- barycentric evaluation over a host-built Delaunay history DAG ------- */
 /* One 64-byte record per DAG node (see DESIGN.md "HBM layout"). */

@@ -100,3 +100,51 @@ def test_check_delaunay_reference_entry_runs_on_device(pkg, orc):
     t = pkg.SimplexTree(2, 2000)
     assert t.init(x, flags=0, rng=pkg.capi.Rng(0)) == 0
     assert pkg.lib().check_delaunay(t._t, t._m()) == 1
+
+
+def test_host_batches_pipelined_over_the_copy_pipe_are_bit_identical(pkg, orc):
+    """Round 4: a host batch on ONE device is cut into chunks whose H2D | sweep | D2H overlap (copy pipe; dense caller
+    arrays travel as they are, strided ones through pinned staging).  A value depends on (model, target) only, so the
+    result must equal the resident one-shot sweep bit for bit -- for the barycentric and the RBF types, dense and
+    strided arguments, with and without the leaf output, and the EDOM verdict must survive the chunking."""
+    import torch
+    n, m = 3000, 1_200_000                                        # >= 2 chunks of 2^19
+    x = orc.synth_centres(n, 2)
+    f = orc.synth_response(x)
+    y = orc.synth_targets(0, m, 2)
+    bits = lambda a: a.view(np.uint64)
+    # --- barycentric
+    t = pkg.SimplexTree(2, n)
+    assert t.init(x, flags=0, rng=pkg.capi.Rng(0)) == 0
+    d = t.device_alloc(0)
+    assert d.set_response(f) == 0
+    ty = torch.from_numpy(y).cuda()
+    tv = torch.empty(m, dtype=torch.float64, device="cuda")
+    tl = torch.empty(m, dtype=torch.int32, device="cuda")
+    assert d.eval_resident(ty.data_ptr(), m, 2, tv.data_ptr(), tl.data_ptr()) == 0
+    torch.cuda.synchronize()
+    rv, rl = tv.cpu().numpy(), tl.cpu().numpy()
+    st, v, l = d.eval_many(y)
+    assert st == 0 and np.array_equal(bits(v), bits(rv)) and np.array_equal(l, rl)
+    wide = np.zeros((m, 3)); wide[:, :2] = y                     # tda = 3: the staged route
+    vs = np.zeros(2 * m)
+    st, v2, l2 = d.eval_many(wide[:, :2], out=(vs[::2], np.empty(m, dtype=np.int32)))
+    assert st == 0 and np.array_equal(bits(np.ascontiguousarray(v2)), bits(rv)) and np.array_equal(l2, rl)
+    st, v3, _ = d.eval_many(y, want_leaf=False)
+    assert st == 0 and np.array_equal(bits(v3), bits(rv))
+    yo = y.copy(); yo[m - 5] = [1e9, 1e9]                         # one target outside the cage, in the last chunk
+    st, v4, l4 = d.eval_many(yo)
+    assert st == pkg.GSL_EDOM and l4[m - 5] == -1 and np.isnan(v4[m - 5]) and np.array_equal(l4[:m - 5], rl[:m - 5])
+    st, v5, _ = d.eval_many(yo, want_leaf=False)                  # the verdict does not need the indices on the host
+    assert st == pkg.GSL_EDOM
+    # --- Gaussian RBF through the facade
+    s = pkg.Sinterp("gaussian", 2, n, 0)
+    assert s.init(x, f) == 0
+    ts = torch.empty(m, dtype=torch.float64, device="cuda")
+    assert s.eval_resident(ty.data_ptr(), m, 2, ts.data_ptr()) == 0
+    torch.cuda.synchronize()
+    rs = ts.cpu().numpy()
+    st, g, _ = s.eval_many(y)
+    assert st == 0 and np.array_equal(bits(g), bits(rs))
+    st, g2, _ = s.eval_many(wide[:, :2], out=vs[::2])
+    assert st == 0 and np.array_equal(bits(np.ascontiguousarray(g2)), bits(rs))
