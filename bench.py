@@ -440,6 +440,24 @@ def committed_pmc(name, kernel):
     return out or None
 
 
+TPS_VALU_PER_PAIR = {1: 17.25, 2: 19.25, 3: 21.25}       # rbf_eval_kernel<TPS, dim, 2>: VALU instructions of the inner loop / 4 pairs
+GAUSS_VALU_PER_PAIR = {2: (6.5, 20.0), 3: (9.0, 20.0)}    # rbf_eval_gauss_cull_kernel: (cut-off pre-test, exp2 evaluation) per pair-slot
+
+
+def gauss_pair_counts(name, n, dim, m_rank):
+    """Pair counts of the culled sweep from the committed counter run (profiles/r04_gauss_pairs.json: the prof build's
+    counters on the same synthetic clouds), scaled to this rank's share of the targets."""
+    path = os.path.join(ROOT, "profiles", "r04_gauss_pairs.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get(name)
+    if not rec or rec["n"] != n or rec["dim"] != dim:
+        return None
+    f = m_rank / rec["m"]
+    return {"staged_pairs": rec["staged_pairs"] * f, "evaluated_pair_lanes": rec["evaluated_pair_lanes"] * f,
+            "useful_pairs": rec["useful_pairs"] * f, "source": "profiles/r04_gauss_pairs.json"}
+
+
 def rooflines(cfg, name, n, dim, m_rank, ph, extra=None, gemm=None):
     """Roofline objects from live HIP-event timings.  Algorithmic work per SURVEY.md 8(d)."""
     res = {}
@@ -477,16 +495,33 @@ def rooflines(cfg, name, n, dim, m_rank, ph, extra=None, gemm=None):
     hbm = {"achieved": round(by / te / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / te / 1e9 / HBM_PEAK_GBS, 6),
            "note": "algorithmic bytes 8d+8 per target; ~1e-3 of the HBM roofline by construction (N pair evaluations per target)"}
     pmc = committed_pmc(name, ek)
-    if gauss:
-        # tiles of centres beyond the 2^-72 cut-off are culled: the surviving pair count is data dependent, so the
-        # honest fixed yardstick is the north star's own (HBM bytes of the target stream); pair rate reported beside it
+    pairs = gauss_pair_counts(name, n, dim, m_rank) if gauss else None
+    if gauss and pairs:
+        # culled sweep: VALU-issue bound on what survives the culling.  Lane-instructions = staged pair-slots x the
+        # cut-off pre-test + evaluated pair-slots x the exp2 evaluation (both counted in the ISA of the inner loop),
+        # pair counts from the committed counter run of the prof build (tools/gauss_pairs.py, same clouds)
+        pre, ev = GAUSS_VALU_PER_PAIR[dim]
+        lane_instr = pairs["staged_pairs"] * pre + pairs["evaluated_pair_lanes"] * ev
+        ach = lane_instr / te
+        r_eval = {"kernel": ek + " (+ two-level reorder of the targets and un-sort, inside the timed phase)", "bound": "valu",
+                  "achieved": round(ach, 1), "peak": VALU_PEAK_LANE_INSTR, "unit": "fp64 lane-instructions/s",
+                  "frac": round(ach / VALU_PEAK_LANE_INSTR, 4),
+                  "valu_instr_per_staged_pair": pre, "valu_instr_per_evaluated_pair": ev,
+                  "pairs": pairs, "algorithmic_pair_evals_per_s": round(pair_ops / te, 1),
+                  "traffic": pmc.get("hbm_traffic_bytes_per_launch") if pmc else None, "committed_pmc": pmc, "hbm": hbm,
+                  "note": "the tile culling leaves %.1f%% of the N x M pairs staged, the per-centre wave test evaluates %.2f%%; "
+                          "%.0f%% of the evaluated lane slots are pairs inside the 2^-72 cut-off" %
+                          (100.0 * pairs["staged_pairs"] / pair_ops, 100.0 * pairs["evaluated_pair_lanes"] / pair_ops,
+                           100.0 * pairs["useful_pairs"] / max(pairs["evaluated_pair_lanes"], 1))}
+    elif gauss:
         r_eval = dict(hbm, kernel=ek + " (+ cell sort of the targets)", bound="hbm",
                       traffic=pmc.get("hbm_traffic_bytes_per_launch") if pmc else None, committed_pmc=pmc,
                       algorithmic_pair_evals_per_s=round(pair_ops / te, 1))
-        r_eval["note"] = ("VALU-bound on the surviving (un-culled) pairs, not HBM-bound: " + hbm["note"])
+        r_eval["note"] = ("VALU-bound on the surviving (un-culled) pairs, not HBM-bound (no committed pair counts for this shape): " + hbm["note"])
     else:
-        # thin-plate sweep: VALU-issue bound.  ~20 VALU instructions per pair (2-D; ISA count of the inner loop)
-        ipp = 17 + 3 * (dim - 1)
+        # thin-plate sweep: VALU-issue bound.  VALU instructions per pair counted in the ISA of the inner loop
+        # (2 centres x 2 targets per iteration; 2-D: 77 / 4 -- 15 fp64 + 4.25 32-bit ops)
+        ipp = TPS_VALU_PER_PAIR[dim]
         ach = pair_ops * ipp / te
         r_eval = {"kernel": ek, "bound": "valu", "achieved": round(ach, 1), "peak": VALU_PEAK_LANE_INSTR,
                   "unit": "fp64 lane-instructions/s", "frac": round(ach / VALU_PEAK_LANE_INSTR, 4),
@@ -500,6 +535,11 @@ def rooflines(cfg, name, n, dim, m_rank, ph, extra=None, gemm=None):
         res["init_as_a_unit"] = {"flops": flops, "tflops": round(flops / tf / 1e12, 4),
                                  "frac_of_fp64_mfma_peak": round(flops / tf / 1e12 / FP64_PEAK_TFLOPS, 5),
                                  "route": {1: "cholesky", 2: "shifted-SPD cholesky + Woodbury", 3: "pivoted LU"}.get(route, "?")}
+        if gemm_dominant:
+            # the object a reader wants first: fill + factorisation + solves as ONE unit against the fp64 MFMA peak; the
+            # single top-level launch (37.5 % of the flops, timed alone on random operands) stays beside it
+            res["roofline"] = dict(res["roofline"], init_as_a_unit=res["init_as_a_unit"],
+                                   frac_kernel=res["roofline"]["frac"], frac_init_as_a_unit=res["init_as_a_unit"]["frac_of_fp64_mfma_peak"])
         res["solve_gflops"] = round(flops / tf / 1e9, 2)
     res["eval_only_mpts"] = round(m_rank / te / 1e6, 3)
     return res

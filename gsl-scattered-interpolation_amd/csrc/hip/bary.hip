@@ -218,6 +218,7 @@ __device__ __forceinline__ NodeRec load_rec(const NodeRec *__restrict__ rec, int
    [JUMP_DELTA, 1 - JUMP_DELTA] at the corners).  By induction the reference walk of ANY target in the
    cell passes through the recorded node with the same persistent coordinates, so starting there
    changes no result.  JUMP_DELTA = 1e-7 is eight orders above the rounding of a well-conditioned 2x2 solve (and the cage, whose barycentric coordinates over the data are ~1e-4, still classifies). */
+#define JUMP_CELLS_PER_NODE 90.0   /* resolution of the table built by tree_pack: see the comment there */
 #define JUMP_DELTA 1e-7
 #define JUMP_SLACK 1e-6
 
@@ -227,33 +228,43 @@ __device__ __forceinline__ double key_to_double(unsigned long long k)   /* inver
   return __longlong_as_double((long long)u);
 }
 
-/* +1: the enlarged cell is provably inside the node's simplex, -1: provably outside, 0: undecided */
+/* +1: the enlarged cell is provably inside the node's simplex, -1: provably outside, 0: undecided.
+   The certificates carry margins of 1e-7 (JUMP_DELTA) and the affinity check one of 1e-9, so the coordinates here are
+   formed with the node's two reciprocals (1 ulp from solve_node's quotients) instead of ten IEEE divisions per node:
+   the table only ever decides where a walk STARTS, every decision of the walk itself uses the exact arithmetic. */
 __device__ __forceinline__ int classify_cell(const NodeRec &r, const double (&cx)[2], const double (&cy)[2], double s0, double s1)
 {
+  const bool sw = META_SWAPPED(r.meta);
+  const double i11 = 1.0 / r.u11, i00 = 1.0 / r.u00;
+  auto coords = [&](double y0, double y1, double &c0, double &c1) {
+    const double b0 = (y0 - r.x0) * s0, b1 = (y1 - r.x1) * s1;
+    double t0 = sw ? b1 : b0, t1 = sw ? b0 : b1;
+    t1 = (t1 - r.l10 * t0) * i11;
+    t0 = (t0 - r.u01 * t1) * i00;
+    c0 = t0; c1 = t1;
+  };
   bool in = true;
   double mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  double m0 = 0.0, m1 = 0.0;
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++) {
       double c0, c1;
-      solve_node(r, cx[a], cy[b], s0, s1, c0, c1);
+      coords(cx[a], cy[b], c0, c1);
       const double c2 = 1.0 - c0 - c1;
       in = in && (c0 >= JUMP_DELTA) && (c1 >= JUMP_DELTA) && (c2 >= JUMP_DELTA);     /* NaN -> false */
       mx[0] = fmax(mx[0], c0 == c0 ? c0 : INFINITY);
       mx[1] = fmax(mx[1], c1 == c1 ? c1 : INFINITY);
       mx[2] = fmax(mx[2], c2 == c2 ? c2 : INFINITY);
+      m0 += 0.25 * c0; m1 += 0.25 * c1;
     }
   /* The argument needs the computed coordinates to be affine in the target up to an error far below
      JUMP_DELTA.  For a badly conditioned (sliver) node that is not a given: check it -- the coordinates
      of the cell centre must equal the mean of the corners' to 1e-9, else the node is left undecided. */
   {
-    double c0, c1, m0 = 0.0, m1 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 2; b++) { solve_node(r, cx[a], cy[b], s0, s1, c0, c1); m0 += 0.25 * c0; m1 += 0.25 * c1; }
-    solve_node(r, 0.5 * (cx[0] + cx[1]), 0.5 * (cy[0] + cy[1]), s0, s1, c0, c1);
+    double c0, c1;
+    coords(0.5 * (cx[0] + cx[1]), 0.5 * (cy[0] + cy[1]), c0, c1);
     if (!(fabs(c0 - m0) <= 1e-9 && fabs(c1 - m1) <= 1e-9)) return 0;
   }
   if (in) return 1;
@@ -263,18 +274,23 @@ __device__ __forceinline__ int classify_cell(const NodeRec &r, const double (&cx
 
 __global__ void __launch_bounds__(256)
 jump_build_kernel(int n_nodes, const NodeRec *__restrict__ rec, double s0, double s1, const unsigned long long *__restrict__ box,
-                  int G, int *__restrict__ jump)
+                  int G, int *__restrict__ jump, const int *__restrict__ coarse, int Gc)
 {
-  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= G * G) return;
-  const int ix = cell % G, iy = cell / G;
+  const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= (size_t)G * G) return;
+  const int ix = (int)(cell % G), iy = (int)(cell / G);
   const double lo0 = key_to_double(box[0]), hi0 = key_to_double(box[1]), lo1 = key_to_double(box[2]), hi1 = key_to_double(box[3]);
   const double w0 = (hi0 - lo0) / G, w1 = (hi1 - lo1) / G;
   const double cx[2] = {lo0 + w0 * ix - JUMP_SLACK * w0, lo0 + w0 * (ix + 1) + JUMP_SLACK * w0};
   const double cy[2] = {lo1 + w1 * iy - JUMP_SLACK * w1, lo1 + w1 * (iy + 1) + JUMP_SLACK * w1};
   int node = 0;
-  NodeRec cur = load_rec(rec, 0);
-  if (!(w0 >= 0.0 && w1 >= 0.0) || META_SINGULAR(cur.meta) || classify_cell(cur, cx, cy, s0, s1) != 1) { jump[cell] = 0; return; }
+  if (coarse) {
+    const int r = G / Gc;
+    node = coarse[(size_t)(iy / r) * Gc + ix / r];
+    if (!(node > 0 && node < n_nodes)) node = 0;
+  }
+  NodeRec cur = load_rec(rec, node);
+  if (node == 0 && (!(w0 >= 0.0 && w1 >= 0.0) || META_SINGULAR(cur.meta) || classify_cell(cur, cx, cy, s0, s1) != 1)) { jump[cell] = 0; return; }
   for (int guard = 0; guard < 4096 && META_TYPE(cur.meta) != 0; guard++) {
     const int nc = META_NCHILD(cur.meta);
     int next = -1;
@@ -820,9 +836,20 @@ extern "C" int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
        longer stays in the Infinity Cache).  160 cells per node, at most 8192^2 (256 MB, built once per tree in ~50 ms).
        Developer knobs: GSL_SINTERP_JUMP_GMAX / GSL_SINTERP_JUMP_FACTOR */
     const int gcap = getenv("GSL_SINTERP_JUMP_GMAX") ? atoi(getenv("GSL_SINTERP_JUMP_GMAX")) : 8192;
-    const double gfac = getenv("GSL_SINTERP_JUMP_FACTOR") ? atof(getenv("GSL_SINTERP_JUMP_FACTOR")) : 160.0;
-    while (G < gcap && (double)G * G < gfac * (double)n_nodes) G *= 2;
-    const size_t bytes = 64 + (size_t)G * G * sizeof(int);
+    const double gfac = getenv("GSL_SINTERP_JUMP_FACTOR") ? atof(getenv("GSL_SINTERP_JUMP_FACTOR")) : JUMP_CELLS_PER_NODE;
+    while (G < gcap && G < 512 && (double)(2 * G) * (2 * G) <= gfac * (double)n_nodes) G *= 2;
+    if (G >= 512) {                                      /* above 512: multiples of 512 (the coarser levels divide by 4) */
+      const int want = (int)(sqrt(gfac * (double)n_nodes) / 512.0) * 512;
+      G = want < 512 ? 512 : (want > gcap ? gcap : want);
+    }
+    /* levels of the hierarchical build: ..., G / 16, G / 4, G (the coarser tables live behind the final one) */
+    static const bool flat = getenv("GSL_SINTERP_JUMP_FLAT") && getenv("GSL_SINTERP_JUMP_FLAT")[0] == '1';   /* developer: every cell from the root */
+    int lev[8], nlev = 0;
+    lev[nlev++] = G;
+    if (!flat) while (nlev < 8 && lev[nlev - 1] >= 512) { lev[nlev] = lev[nlev - 1] / 4; nlev++; }
+    size_t cells = 0;
+    for (int i = 0; i < nlev; i++) cells += (size_t)lev[i] * lev[i];
+    const size_t bytes = 64 + cells * sizeof(int);
     if (bytes > ctx->jumpt_bytes) {
       if (ctx->d_jumpt) { HIP_OK(ctx, hipStreamSynchronize(ctx->stream)); HIP_OK(ctx, hipFree(ctx->d_jumpt)); ctx->d_jumpt = NULL; ctx->jumpt_bytes = 0; }
       HIP_OK(ctx, hipMalloc(&ctx->d_jumpt, bytes));
@@ -831,9 +858,15 @@ extern "C" int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
     unsigned long long *d_box = (unsigned long long *)ctx->d_jumpt;
     int st = sinterp_bbox_keys(ctx, d_points, (size_t)n_points, 2, 2, d_box);
     if (st) return st;
-    hipLaunchKernelGGL(jump_build_kernel, dim3((unsigned)(((size_t)G * G + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes,
-                       (const NodeRec *)d_records, g.scale[0], g.scale[1], (const unsigned long long *)d_box, G,
-                       (int *)((char *)ctx->d_jumpt + 64));
+    int *tab[8];
+    tab[0] = (int *)((char *)ctx->d_jumpt + 64);
+    for (int i = 1; i < nlev; i++) tab[i] = tab[i - 1] + (size_t)lev[i - 1] * lev[i - 1];
+    for (int i = nlev - 1; i >= 0; i--) {                 /* coarsest first; level i starts from level i + 1 */
+      const int Gi = lev[i];
+      hipLaunchKernelGGL(jump_build_kernel, dim3((unsigned)(((size_t)Gi * Gi + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes,
+                         (const NodeRec *)d_records, g.scale[0], g.scale[1], (const unsigned long long *)d_box, Gi, tab[i],
+                         i + 1 < nlev ? (const int *)tab[i + 1] : (const int *)NULL, i + 1 < nlev ? lev[i + 1] : 0);
+    }
     LAUNCH_CHECK(ctx);
     ctx->jump_rec = d_records; ctx->jump_nodes = n_nodes; ctx->jump_G = G;
   }
@@ -910,7 +943,7 @@ static int bary_eval_part(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_r
     if (st) return st;
     d_jump = (int *)jb;
     hipLaunchKernelGGL(jump_build_kernel, dim3((unsigned)((G * G + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes,
-                       (const NodeRec *)d_records, h_scale[0], h_scale[1], (const unsigned long long *)srt.box, G, d_jump);
+                       (const NodeRec *)d_records, h_scale[0], h_scale[1], (const unsigned long long *)srt.box, G, d_jump, (const int *)NULL, 0);
     d_jbox = srt.box;
   }
   size_t blocks = (m + 255) / 256;
@@ -1127,7 +1160,7 @@ __global__ void mesh_seed_fill_kernel(const int *__restrict__ seed_in, int *__re
 }
 
 __device__ __forceinline__ void mesh_finish(const NodeRec &cur, const LeafRec *__restrict__ tab, int t, double y0, double y1, double s0,
-                                            double s1, size_t k, double *__restrict__ values, int *__restrict__ tri_out)
+                                            double s1, size_t k, double *__restrict__ values, int *__restrict__ tri_out, int packed)
 {
   double c0, c1;
   solve_node(cur, y0, y1, s0, s1, c0, c1);
@@ -1138,16 +1171,17 @@ __device__ __forceinline__ void mesh_finish(const NodeRec &cur, const LeafRec *_
   tot += c1;
   if (lr.mask & 2) interp += c1 * lr.f[1];
   if (lr.mask & 4) interp += (1 - tot) * lr.f[2];
-  values[k] = interp;
-  if (tri_out) tri_out[k] = t;
+  store_result(values, tri_out, k, interp, t, packed);
 }
 
-/* todo: [0] = count, [1..] = indices of the targets left to the exhaustive scan */
+/* todo: [0] = count, [1..] = indices of the targets left to the exhaustive scan.  packed: store_result's modes (batches of
+   >= 4096 targets arrive in grid-cell order like the DAG path's: neighbouring lanes then start from neighbouring seeds and
+   walk through the same few triangles -- their 64-byte records are shared by the wave instead of one cache line per lane) */
 __global__ void __launch_bounds__(256)
 mesh_walk_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, const int *__restrict__ seed, MeshGrid g,
                  double s0, double s1, int convex, int max_steps, const double *__restrict__ targets, size_t m, size_t ttda,
                  double *__restrict__ values, int *__restrict__ tri_out, unsigned long long *__restrict__ n_outside,
-                 unsigned *__restrict__ todo)
+                 unsigned *__restrict__ todo, int packed)
 {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
@@ -1194,14 +1228,13 @@ mesh_walk_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__re
     prev = t; prev_viol = viol;
     t = next;
   }
-  if (found >= 0) { mesh_finish(cur, tab, found, y0, y1, s0, s1, k, values, tri_out); return; }
+  if (found >= 0) { mesh_finish(cur, tab, found, y0, y1, s0, s1, k, values, tri_out, packed); return; }
   if (found == -3) {
     const unsigned slot = atomicAdd(&todo[0], 1u);
     todo[1 + slot] = (unsigned)k;
     return;
   }
-  values[k] = __longlong_as_double(0x7ff8000000000000LL);
-  if (tri_out) tri_out[k] = -1;
+  store_result(values, tri_out, k, __longlong_as_double(0x7ff8000000000000LL), -1, packed);
   atomicAdd(n_outside, 1ULL);
 }
 
@@ -1210,7 +1243,7 @@ mesh_walk_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__re
 __global__ void __launch_bounds__(256)
 mesh_scan_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, double s0, double s1,
                  const double *__restrict__ targets, size_t ttda, double *__restrict__ values, int *__restrict__ tri_out,
-                 unsigned long long *__restrict__ n_outside, const unsigned *__restrict__ todo)
+                 unsigned long long *__restrict__ n_outside, const unsigned *__restrict__ todo, int packed)
 {
   __shared__ unsigned long long s_viol;
   __shared__ int s_best;
@@ -1236,10 +1269,9 @@ mesh_scan_kernel(int n_tri, const NodeRec *__restrict__ rec, const LeafRec *__re
     __syncthreads();
     if (threadIdx.x == 0) {
       const int t = s_best;
-      if (t != 0x7fffffff && __longlong_as_double((long long)s_viol) <= MESH_GAP) mesh_finish(load_rec(rec, t), tab, t, y0, y1, s0, s1, k, values, tri_out);
+      if (t != 0x7fffffff && __longlong_as_double((long long)s_viol) <= MESH_GAP) mesh_finish(load_rec(rec, t), tab, t, y0, y1, s0, s1, k, values, tri_out, packed);
       else {
-        values[k] = __longlong_as_double(0x7ff8000000000000LL);
-        if (tri_out) tri_out[k] = -1;
+        store_result(values, tri_out, k, __longlong_as_double(0x7ff8000000000000LL), -1, packed);
         atomicAdd(n_outside, 1ULL);
       }
     }
@@ -1294,15 +1326,34 @@ extern "C" int gsl_sinterp_hip_mesh_eval(gsl_sinterp_hip_ctx *ctx, int n_tri, co
   HIP_OK(ctx, hipMemsetAsync(todo, 0, sizeof(unsigned), ctx->stream));
   MeshGrid mg;
   mg.lo0 = h_geom[4]; mg.lo1 = h_geom[5]; mg.w0 = (h_geom[6] - h_geom[4]) / G; mg.w1 = (h_geom[7] - h_geom[5]) / G; mg.G = G;
-  /* a straight walk from a grid seed crosses a handful of triangles; the bound only guards against cycles */
+  /* batches of >= 4096 targets: the DAG path's reorder (cell order, two-level from 2^18 targets), results through the
+     order's map, un-sorted afterwards.  A result depends on (mesh, target) only: same bits either way. */
+  const bool will_sort = m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1');
+  sinterp_sorted srt;
+  if (will_sort) {
+    st = sinterp_sort_reorder(ctx, d_targets, m, ttda, 2, 64, &srt, m, -1, (const unsigned long long *)NULL);
+    if (st) return st;
+  }
+  const double *yt = will_sort ? (const double *)srt.ys : d_targets;
+  const size_t yl = will_sort ? (size_t)2 : ttda;
+  const bool via_map = will_sort && srt.two_level;
+  double *vt = will_sort ? (via_map ? srt.res1 : srt.vs) : d_values;
+  int *lt = will_sort ? (via_map ? (int *)srt.inv : (int *)NULL) : d_tri;
+  const int packed = (will_sort && d_tri != NULL ? 1 : 0) | (via_map ? 2 : 0);
+  /* a straight walk from a grid seed crosses a handful of triangles; the bound only guards against cycles (an imported
+     non-Delaunay mesh can make the walk circle: such targets go to the exhaustive scan after 64 + 4 G steps at most) */
   const int max_steps = 64 + 4 * G;
   hipLaunchKernelGGL(mesh_walk_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, n_tri, (const NodeRec *)d_records,
-                     (const LeafRec *)d_leaftab, d_seed, mg, h_geom[2], h_geom[3], convex, max_steps, d_targets, m, ttda, d_values,
-                     d_tri, d_count, todo);
+                     (const LeafRec *)d_leaftab, d_seed, mg, h_geom[2], h_geom[3], convex, max_steps, yt, m, yl, vt,
+                     lt, d_count, todo, packed);
   hipLaunchKernelGGL(mesh_scan_kernel, dim3(256), dim3(256), 0, ctx->stream, n_tri, (const NodeRec *)d_records,
-                     (const LeafRec *)d_leaftab, h_geom[2], h_geom[3], d_targets, ttda, d_values, d_tri, d_count,
-                     (const unsigned *)todo);
+                     (const LeafRec *)d_leaftab, h_geom[2], h_geom[3], yt, yl, vt, lt, d_count,
+                     (const unsigned *)todo, packed);
   LAUNCH_CHECK(ctx);
+  if (will_sort) {
+    st = (packed & 1) ? sinterp_unsort_packed(ctx, &srt, m, d_values, d_tri) : sinterp_unsort(ctx, &srt, m, d_values, d_tri);
+    if (st) return st;
+  }
   if (h_n_outside) {
     unsigned long long c = 0;
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
