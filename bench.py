@@ -344,6 +344,10 @@ def main():
                 out["facade_host_mpts"] = {k: facade_host_path(env, k) for k in ("C4", "C5")}
             except Exception as exc:                      # never let the side measurement take the line down
                 out["facade_host_mpts"] = {"error": repr(exc)}
+            try:
+                out["extra"]["imported_mesh_C5M"] = mesh_figure(env)
+            except Exception as exc:
+                out["extra"]["imported_mesh_C5M"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(CONFIGS[headline], head["n_centres"], head["dim"], head["targets_total"])
         print(json.dumps(out))
@@ -404,6 +408,49 @@ def facade_host_path(env, name, reps=3):
             "frac_of_pcie_bound": round(ms_pcie / ms, 4),
             "note": "host gsl_matrix in, host gsl_vector out through the C facade (pageable memory, dense rows); the bound is "
                     "torch's H2D + D2H of the same arrays, serial, measured in this run"}
+
+
+def mesh_figure(env, steps=10):
+    """Imported triangulations at C5's shape: the final triangulation of the N = 50 000 tree exported as a mesh
+    (simplex_mesh_from_tree), M = 10^7 resident targets through the seed grid + leaf-adjacency walk; checked against the
+    DAG path on a sample (same leaf -> same bits)."""
+    import numpy as np
+    torch, pkg, ctx = env.torch, env.pkg, env.ctx
+    n, m = CONFIGS["C5"]["n"], CONFIGS["C5"]["m"]
+    d_x = torch.empty((n, 2), dtype=torch.float64, device="cuda")
+    d_y = torch.empty((m, 2), dtype=torch.float64, device="cuda")
+    ctx.synth_unit(0xC0FFEE01, 0, 0.0, 1.0, d_x.data_ptr(), n * 2)
+    ctx.synth_unit(0xC0FFEE02, 0, 0.02, 0.96, d_y.data_ptr(), m * 2)
+    x = d_x.cpu().numpy()
+    f = np.sin(3.0 * x[:, 0]) + np.sin(6.0 * x[:, 1])
+    tree = pkg.SimplexTree(2, n)
+    assert tree.init(x, flags=0, rng=pkg.capi.Rng(0)) == 0
+    mesh = pkg.SimplexMesh.from_tree(tree)
+    dev = mesh.device_alloc(0)
+    assert dev.set_response(f) == 0
+    d_v = torch.empty(m, dtype=torch.float64, device="cuda")
+    d_t = torch.empty(m, dtype=torch.int32, device="cuda")
+    run = lambda: dev.eval_resident(d_y.data_ptr(), m, 2, d_v.data_ptr(), d_t.data_ptr())
+    assert run() == 0
+    pkg.lib().gsl_sinterp_hip_sync(dev.ctx_handle())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert run() == 0
+    pkg.lib().gsl_sinterp_hip_sync(dev.ctx_handle())
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    # the DAG path on a sample: identical values wherever the mesh found a triangle
+    tdev = tree.device_alloc(0)
+    assert tdev.set_response(f) == 0
+    idx = np.arange(0, m, 9973)
+    ys = np.ascontiguousarray(d_y.cpu().numpy()[idx])
+    _, dag_v, _ = tdev.eval_many(ys)
+    got = d_v.cpu().numpy()[idx]
+    tri = d_t.cpu().numpy()[idx]
+    same = bool(np.array_equal(got[tri >= 0].view(np.uint64), dag_v[tri >= 0].view(np.uint64)))
+    return {"workload": "C5M: the final triangulation of C5's tree exported as an imported mesh, M = 10M resident targets",
+            "n_triangles": mesh.n_triangles, "ms_per_step": round(ms, 4), "mpts": round(m / ms / 1e3, 2),
+            "values_equal_dag_path_on_sample": same, "targets_outside_mesh_in_sample": int((tri < 0).sum())}
 
 
 def time_top_gemm(ctx, n, reps=3):

@@ -203,6 +203,11 @@ SIGNATURES = {
     "simplex_mesh_set_convex": (None, [_vp, _i]),
     "simplex_mesh_convex": (_i, [_vp]),
     "simplex_mesh_device_alloc": (_vp, [_vp, _i]),
+    "simplex_mesh_device_alloc_multi": (_vp, [_vp, _pi, _i]),
+    "simplex_mesh_device_n_devices": (_i, [_vp]),
+    "simplex_mesh_fwrite": (_i, [_vp, _vp]),
+    "simplex_mesh_fread": (_vp, [_vp]),
+    "gsl_sinterp_set_triangulation": (_i, [C.POINTER(gsl_sinterp), _pi, _pi, _sz]),
     "simplex_mesh_device_free": (None, [_vp]),
     "simplex_mesh_device_set_response": (_i, [_vp, _pv]),
     "simplex_mesh_device_eval_many": (_i, [_vp, _pm, _pv, _pi]),
@@ -250,7 +255,7 @@ SIGNATURES = {
     "gsl_rng_get": (C.c_ulong, [_vp]),
     "gsl_rng_uniform_int": (C.c_ulong, [_vp, C.c_ulong]),
 }
-DATA_SYMBOLS = ["gsl_sinterp_kriging", "gsl_sinterp_rbf_gaussian", "gsl_sinterp_rbf_tps", "gsl_sinterp_rbf_tps_affine", "gsl_sinterp_rbf_wendland", "gsl_sinterp_linear_simplex",
+DATA_SYMBOLS = ["gsl_sinterp_kriging", "gsl_sinterp_linear_mesh", "gsl_sinterp_rbf_gaussian", "gsl_sinterp_rbf_tps", "gsl_sinterp_rbf_tps_affine", "gsl_sinterp_rbf_wendland", "gsl_sinterp_linear_simplex",
                 "gsl_rng_mt19937", "gsl_rng_default"]
 
 
@@ -724,6 +729,23 @@ class SimplexMesh:
             raise GslError(GSL_EFAILED, "simplex_mesh_device_alloc")
         return DeviceMesh(h, self)
 
+    def device_alloc_multi(self, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        h = lib().simplex_mesh_device_alloc_multi(self._h, arr, len(devices))
+        if not h:
+            raise GslError(GSL_EFAILED, "simplex_mesh_device_alloc_multi")
+        return DeviceMesh(h, self)
+
+    def fwrite(self, path):
+        with CFile(path, "wb") as fp:
+            return lib().simplex_mesh_fwrite(fp, self._h)
+
+    @classmethod
+    def fread(cls, path):
+        with CFile(path, "rb") as fp:
+            h = lib().simplex_mesh_fread(fp)
+        return cls(h) if h else None
+
     def close(self):
         if self._h:
             lib().simplex_mesh_free(self._h)
@@ -744,12 +766,15 @@ class DeviceMesh:
     def set_response(self, response):
         return lib().simplex_mesh_device_set_response(self._h, C.byref(as_vector(response)))
 
-    def eval_many(self, targets):
+    def eval_many(self, targets, out=None):
         m = targets.shape[0]
-        vals = np.empty(m, dtype=np.float64)
-        tri = np.empty(m, dtype=np.int32)
+        vals = np.empty(m, dtype=np.float64) if out is None else out[0]
+        tri = np.empty(m, dtype=np.int32) if out is None else out[1]
         st = lib().simplex_mesh_device_eval_many(self._h, C.byref(as_matrix(targets)), C.byref(as_vector(vals)), tri.ctypes.data_as(_pi))
         return st, vals, tri
+
+    def n_devices(self):
+        return lib().simplex_mesh_device_n_devices(self._h)
 
     def eval_resident(self, d_targets, m, ttda, d_values, d_tri):
         return lib().simplex_mesh_device_eval_resident(self._h, d_targets, m, ttda, d_values, d_tri)
@@ -772,7 +797,7 @@ class DeviceMesh:
 # ------------------------------------------------------------------ facade
 class Sinterp:
     TYPES = {"gaussian": "gsl_sinterp_rbf_gaussian", "tps": "gsl_sinterp_rbf_tps", "tps_affine": "gsl_sinterp_rbf_tps_affine",
-             "wendland": "gsl_sinterp_rbf_wendland",
+             "wendland": "gsl_sinterp_rbf_wendland", "linear_mesh": "gsl_sinterp_linear_mesh",
              "linear_simplex": "gsl_sinterp_linear_simplex", "kriging": "gsl_sinterp_kriging"}
 
     def __init__(self, kind, dim, size, device=0):
@@ -821,6 +846,12 @@ class Sinterp:
 
     def n_devices(self):
         return lib().gsl_sinterp_n_devices(self._p)
+
+    def set_triangulation(self, triangles, neighbours=None):
+        tri = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        nbr = None if neighbours is None else np.ascontiguousarray(neighbours, dtype=np.int32).reshape(-1, 3)
+        return lib().gsl_sinterp_set_triangulation(self._p, tri.ctypes.data_as(_pi), nbr.ctypes.data_as(_pi) if nbr is not None else None,
+                                                   len(tri))
 
     def set_tree_options(self, flags, rng):
         self._rng = rng

@@ -9,6 +9,8 @@
 #include "gsl_sinterp.h"
 #include <limits.h>
 #include <math.h>
+#include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -35,6 +37,11 @@ const int *simplex_mesh_neighbours(const simplex_mesh *mesh) { return mesh ? mes
 const int *simplex_mesh_tree_nodes(const simplex_mesh *mesh) { return mesh ? mesh->node : NULL; }
 void simplex_mesh_set_convex(simplex_mesh *mesh, int convex) { if (mesh) mesh->convex = convex != 0; }
 int simplex_mesh_convex(const simplex_mesh *mesh) { return mesh ? mesh->convex : 0; }
+const double *simplex_mesh_points(const simplex_mesh *mesh) { return mesh ? mesh->points : NULL; }
+void simplex_mesh_bbox(const simplex_mesh *mesh, double lo[2], double hi[2])
+{
+  for (int j = 0; j < 2; j++) { lo[j] = mesh->lo[j]; hi[j] = mesh->hi[j]; }
+}
 void simplex_mesh_geometry(const simplex_mesh *mesh, double shift[2], double scale[2])
 {
   for (int j = 0; j < 2; j++) { shift[j] = mesh->shift[j]; scale[j] = mesh->scale[j]; }
@@ -182,6 +189,7 @@ simplex_mesh *simplex_mesh_import(const gsl_matrix *points, const int *triangles
         if (nb < 0) continue;
         const int u = m->tri[3 * t + (k + 1) % 3], v = m->tri[3 * t + (k + 2) % 3];
         int ok = 0;
+        if (nb == (int)t) { simplex_mesh_free(m); GSL_ERROR_NULL("simplex_mesh_import: a triangle is its own neighbour", GSL_EINVAL); }
         for (int q = 0; q < 3 && !ok; q++)
           if (m->nbr[3 * nb + q] == (int)t) {
             const int a = m->tri[3 * nb + (q + 1) % 3], b = m->tri[3 * nb + (q + 2) % 3];
@@ -235,128 +243,76 @@ simplex_mesh *simplex_mesh_from_tree(simplex_tree *tree, gsl_matrix *data)
 }
 
 /* ------------------------------------------------------------------------ */
-struct simplex_mesh_device {
-  gsl_sinterp_hip_ctx *ctx;
-  int n_tri, n_points, G, convex;
-  double geom[8];
-  void *d_records, *d_leaftab;
-  int *d_tri, *d_seed;
-  int response_bound;
-};
+/* Binary checkpoint of a mesh (gsl_matrix_fwrite conventions: native byte order, GSL_EFAILED on a short transfer):
+     magic "GSLSMSH1" | n_tri, n_points, has_nodes, convex (int64) | triangles | neighbours | [tree nodes] | points |
+     shift, scale, lo, hi.
+   fread re-checks everything the import checks (ids in range, no repeated vertex, mutual links across the same edge):
+   the locate kernels index with these arrays. */
+static const char MESH_MAGIC[8] = {'G', 'S', 'L', 'S', 'M', 'S', 'H', '1'};
 
-gsl_sinterp_hip_ctx *simplex_mesh_device_ctx(simplex_mesh_device *dev) { return dev ? dev->ctx : NULL; }
-
-void simplex_mesh_device_free(simplex_mesh_device *dev)
+int simplex_mesh_fwrite(FILE *stream, const simplex_mesh *m)
 {
-  if (!dev) return;
-  if (dev->ctx) {
-    gsl_sinterp_hip_free(dev->ctx, dev->d_records); gsl_sinterp_hip_free(dev->ctx, dev->d_leaftab);
-    gsl_sinterp_hip_free(dev->ctx, dev->d_tri); gsl_sinterp_hip_free(dev->ctx, dev->d_seed);
-    gsl_sinterp_hip_ctx_destroy(dev->ctx);
-  }
-  free(dev);
-}
-
-simplex_mesh_device *simplex_mesh_device_alloc(const simplex_mesh *mesh, int device)
-{
-  if (!mesh) GSL_ERROR_NULL("simplex_mesh_device_alloc: null mesh", GSL_EFAULT);
-  simplex_mesh_device *dev = (simplex_mesh_device *)calloc(1, sizeof *dev);
-  if (!dev) GSL_ERROR_NULL("simplex_mesh_device_alloc: out of memory", GSL_ENOMEM);
-  dev->n_tri = (int)mesh->n_tri; dev->n_points = (int)mesh->n_points; dev->convex = mesh->convex;
-  /* about two triangles per seed cell */
-  int G = (int)ceil(sqrt((double)mesh->n_tri / 2.0));
-  dev->G = G < 1 ? 1 : (G > 2048 ? 2048 : G);
-  dev->geom[0] = mesh->shift[0]; dev->geom[1] = mesh->shift[1]; dev->geom[2] = mesh->scale[0]; dev->geom[3] = mesh->scale[1];
-  dev->geom[4] = mesh->lo[0]; dev->geom[5] = mesh->lo[1]; dev->geom[6] = mesh->hi[0]; dev->geom[7] = mesh->hi[1];
-  if (gsl_sinterp_hip_ctx_create(&dev->ctx, device, NULL) != GSL_SUCCESS) {
-    free(dev);
-    GSL_ERROR_NULL("simplex_mesh_device_alloc: no usable HIP device (GPU path has no CPU fallback)", GSL_EFAILED);
-  }
-  gsl_sinterp_hip_ctx *c = dev->ctx;
-  const size_t tb = 3 * mesh->n_tri * sizeof(int), pb = 2 * mesh->n_points * sizeof(double);
-  int *d_nbr = NULL;
-  double *d_pts = NULL;
-  int st = gsl_sinterp_hip_malloc(c, (void **)&dev->d_tri, tb);
-  if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_nbr, tb);
-  if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_pts, pb);
-  if (!st) st = gsl_sinterp_hip_malloc(c, &dev->d_records, mesh->n_tri * GSL_SINTERP_TREE_RECORD_BYTES);
-  if (!st) st = gsl_sinterp_hip_malloc(c, &dev->d_leaftab, mesh->n_tri * GSL_SINTERP_TREE_LEAFTAB_BYTES);
-  if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&dev->d_seed, 2 * (size_t)dev->G * dev->G * sizeof(int));
-  if (!st) st = gsl_sinterp_hip_h2d(c, dev->d_tri, mesh->tri, tb);
-  if (!st) st = gsl_sinterp_hip_h2d(c, d_nbr, mesh->nbr, tb);
-  if (!st) st = gsl_sinterp_hip_h2d(c, d_pts, mesh->points, pb);
-  if (!st) st = gsl_sinterp_hip_mesh_pack(c, dev->n_tri, dev->d_tri, d_nbr, dev->n_points, d_pts, dev->geom, dev->G, dev->d_records, dev->d_seed);
-  if (!st) st = gsl_sinterp_hip_sync(c);
-  gsl_sinterp_hip_free(c, d_nbr); gsl_sinterp_hip_free(c, d_pts);
-  if (st != GSL_SUCCESS) {
-    gsl_error(gsl_sinterp_hip_last_error(c), __FILE__, __LINE__, st);
-    simplex_mesh_device_free(dev);
-    return NULL;
-  }
-  return dev;
-}
-
-int simplex_mesh_device_set_response(simplex_mesh_device *dev, const gsl_vector *response)
-{
-  if (!dev || !response) GSL_ERROR("simplex_mesh_device_set_response: null argument", GSL_EFAULT);
-  if (response->size < (size_t)dev->n_points) GSL_ERROR("simplex_mesh_device_set_response: response shorter than the point set", GSL_EBADLEN);
-  const size_t np = (size_t)dev->n_points;
-  double *h = (double *)malloc(np * sizeof(double)), *d_resp = NULL;
-  if (!h) GSL_ERROR("simplex_mesh_device_set_response: out of memory", GSL_ENOMEM);
-  for (size_t i = 0; i < np; i++) h[i] = response->data[i * response->stride];
-  int st = gsl_sinterp_hip_malloc(dev->ctx, (void **)&d_resp, np * sizeof(double));
-  if (!st) st = gsl_sinterp_hip_h2d(dev->ctx, d_resp, h, np * sizeof(double));
-  if (!st) st = gsl_sinterp_hip_tree_bind(dev->ctx, dev->n_tri, dev->d_tri, dev->n_points, d_resp, dev->d_leaftab);
-  if (!st) st = gsl_sinterp_hip_sync(dev->ctx);
-  gsl_sinterp_hip_free(dev->ctx, d_resp);
-  free(h);
-  if (st) GSL_ERROR(gsl_sinterp_hip_last_error(dev->ctx), st);
-  dev->response_bound = 1;
+  if (!stream || !m) GSL_ERROR("simplex_mesh_fwrite: null argument", GSL_EFAULT);
+  const int64_t head[4] = {(int64_t)m->n_tri, (int64_t)m->n_points, m->node ? 1 : 0, m->convex};
+  int ok = fwrite(MESH_MAGIC, 1, 8, stream) == 8 && fwrite(head, sizeof head[0], 4, stream) == 4;
+  ok = ok && fwrite(m->tri, sizeof(int), 3 * m->n_tri, stream) == 3 * m->n_tri;
+  ok = ok && fwrite(m->nbr, sizeof(int), 3 * m->n_tri, stream) == 3 * m->n_tri;
+  if (m->node) ok = ok && fwrite(m->node, sizeof(int), m->n_tri, stream) == m->n_tri;
+  ok = ok && fwrite(m->points, sizeof(double), 2 * m->n_points, stream) == 2 * m->n_points;
+  double geo[8] = {m->shift[0], m->shift[1], m->scale[0], m->scale[1], m->lo[0], m->lo[1], m->hi[0], m->hi[1]};
+  ok = ok && fwrite(geo, sizeof(double), 8, stream) == 8;
+  if (!ok) GSL_ERROR("simplex_mesh_fwrite: fwrite failed", GSL_EFAILED);
   return GSL_SUCCESS;
 }
 
-int simplex_mesh_device_eval_resident(simplex_mesh_device *dev, const double *d_targets, size_t m, size_t ttda,
-                                      double *d_values, int *d_triangle)
+simplex_mesh *simplex_mesh_fread(FILE *stream)
 {
-  if (!dev) GSL_ERROR("simplex_mesh_device_eval_resident: null device mirror", GSL_EFAULT);
-  if (!dev->response_bound) GSL_ERROR("simplex_mesh_device_eval_resident: no response bound", GSL_EINVAL);
-  int st = gsl_sinterp_hip_mesh_eval(dev->ctx, dev->n_tri, dev->d_records, dev->d_leaftab, dev->d_seed, dev->G, dev->geom, dev->convex,
-                                     d_targets, m, ttda, d_values, d_triangle, NULL);
-  if (st) GSL_ERROR(gsl_sinterp_hip_last_error(dev->ctx), st);
-  return GSL_SUCCESS;
-}
-
-int simplex_mesh_device_eval_many(simplex_mesh_device *dev, const gsl_matrix *targets, gsl_vector *values, int *triangle)
-{
-  if (!dev || !targets || !values) GSL_ERROR("simplex_mesh_device_eval_many: null argument", GSL_EFAULT);
-  if (!dev->response_bound) GSL_ERROR("simplex_mesh_device_eval_many: no response bound", GSL_EINVAL);
-  if (targets->size2 != 2) GSL_ERROR("simplex_mesh_device_eval_many: targets must be M x 2", GSL_EBADLEN);
-  const size_t m = targets->size1;
-  if (values->size != m) GSL_ERROR("simplex_mesh_device_eval_many: values length must equal target rows", GSL_EBADLEN);
-  if (m == 0) return GSL_SUCCESS;
-  gsl_sinterp_hip_ctx *c = dev->ctx;
-  double *h_y = (double *)malloc(2 * m * sizeof(double)), *h_s = (double *)malloc(m * sizeof(double));
-  double *d_y = NULL, *d_s = NULL;
-  int *d_t = NULL;
-  long long n_out = 0;
-  int st = (h_y && h_s) ? GSL_SUCCESS : GSL_ENOMEM;
-  if (!st) for (size_t k = 0; k < m; k++) { h_y[2 * k] = targets->data[k * targets->tda]; h_y[2 * k + 1] = targets->data[k * targets->tda + 1]; }
-  if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_y, 2 * m * sizeof(double));
-  if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_s, m * sizeof(double));
-  if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_t, m * sizeof(int));
-  if (!st) st = gsl_sinterp_hip_h2d(c, d_y, h_y, 2 * m * sizeof(double));
-  int st_eval = GSL_SUCCESS;
-  if (!st) {
-    st_eval = gsl_sinterp_hip_mesh_eval(c, dev->n_tri, dev->d_records, dev->d_leaftab, dev->d_seed, dev->G, dev->geom, dev->convex, d_y, m, 2,
-                                        d_s, d_t, &n_out);
-    if (st_eval != GSL_SUCCESS && st_eval != GSL_EDOM) st = st_eval;
+  if (!stream) GSL_ERROR_NULL("simplex_mesh_fread: null stream", GSL_EFAULT);
+  char magic[8];
+  int64_t head[4];
+  if (fread(magic, 1, 8, stream) != 8 || memcmp(magic, MESH_MAGIC, 8) != 0)
+    GSL_ERROR_NULL("simplex_mesh_fread: not a simplex_mesh checkpoint", GSL_EFAILED);
+  if (fread(head, sizeof head[0], 4, stream) != 4) GSL_ERROR_NULL("simplex_mesh_fread: short header", GSL_EFAILED);
+  if (head[0] < 1 || head[0] > INT_MAX / 3 || head[1] < 3 || head[1] > INT_MAX || (head[2] != 0 && head[2] != 1))
+    GSL_ERROR_NULL("simplex_mesh_fread: corrupt header", GSL_EFAILED);
+  const size_t nt = (size_t)head[0], np = (size_t)head[1];
+  {
+    /* seekable stream: the counts must fit what is left of the file before anything is allocated for them */
+    const long here = ftell(stream);
+    if (here >= 0 && fseek(stream, 0L, SEEK_END) == 0) {
+      const long end = ftell(stream);
+      const long long need = 4LL * (6 + head[2]) * (long long)nt + 16LL * (long long)np + 64;
+      if (fseek(stream, here, SEEK_SET) != 0) GSL_ERROR_NULL("simplex_mesh_fread: stream error", GSL_EFAILED);
+      if (end >= here && (long long)(end - here) < need) GSL_ERROR_NULL("simplex_mesh_fread: short or corrupt checkpoint", GSL_EFAILED);
+    }
   }
-  if (!st) st = gsl_sinterp_hip_d2h(c, h_s, d_s, m * sizeof(double));
-  if (!st && triangle) st = gsl_sinterp_hip_d2h(c, triangle, d_t, m * sizeof(int));
-  if (!st) for (size_t k = 0; k < m; k++) values->data[k * values->stride] = h_s[k];
-  gsl_sinterp_hip_free(c, d_y); gsl_sinterp_hip_free(c, d_s); gsl_sinterp_hip_free(c, d_t);
-  free(h_y); free(h_s);
-  if (st) GSL_ERROR(gsl_sinterp_hip_last_error(c), st);
-  if (st_eval == GSL_EDOM) GSL_ERROR("simplex_mesh_device_eval_many: target(s) outside the triangulation", GSL_EDOM);
-  return GSL_SUCCESS;
+  simplex_mesh *m = mesh_alloc(nt, np, (int)head[2]);
+  if (!m) GSL_ERROR_NULL("simplex_mesh_fread: out of memory", GSL_ENOMEM);
+  double geo[8];
+  int ok = fread(m->tri, sizeof(int), 3 * nt, stream) == 3 * nt && fread(m->nbr, sizeof(int), 3 * nt, stream) == 3 * nt;
+  if (m->node) ok = ok && fread(m->node, sizeof(int), nt, stream) == nt;
+  ok = ok && fread(m->points, sizeof(double), 2 * np, stream) == 2 * np && fread(geo, sizeof(double), 8, stream) == 8;
+  for (size_t i = 0; ok && i < 3 * nt; i++)
+    ok = m->tri[i] >= 0 && (size_t)m->tri[i] < np && m->nbr[i] >= -1 && m->nbr[i] < (int)nt;
+  for (size_t t = 0; ok && t < nt; t++) {
+    const int *v = m->tri + 3 * t;
+    ok = v[0] != v[1] && v[0] != v[2] && v[1] != v[2];
+    for (int k = 0; ok && k < 3; k++) {                          /* links mutual, across the same edge */
+      const int nb = m->nbr[3 * t + k];
+      if (nb < 0) continue;
+      if (nb == (int)t) { ok = 0; break; }                       /* a triangle is not its own neighbour */
+      const int u = v[(k + 1) % 3], w = v[(k + 2) % 3];
+      int found = 0;
+      for (int q = 0; q < 3 && !found; q++)
+        if (m->nbr[3 * nb + q] == (int)t) {
+          const int a = m->tri[3 * nb + (q + 1) % 3], b = m->tri[3 * nb + (q + 2) % 3];
+          found = (a == u && b == w) || (a == w && b == u);
+        }
+      ok = found;
+    }
+  }
+  if (!ok) { simplex_mesh_free(m); GSL_ERROR_NULL("simplex_mesh_fread: short or corrupt checkpoint", GSL_EFAILED); }
+  for (int j = 0; j < 2; j++) { m->shift[j] = geo[j]; m->scale[j] = geo[2 + j]; m->lo[j] = geo[4 + j]; m->hi[j] = geo[6 + j]; }
+  m->convex = head[3] != 0;
+  return m;
 }

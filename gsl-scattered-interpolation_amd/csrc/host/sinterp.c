@@ -13,6 +13,7 @@
  * There is deliberately no CPU evaluation path here.
  */
 #include "gsl_sinterp.h"
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -603,6 +604,171 @@ int simplex_tree_check_device(simplex_tree *tree, gsl_matrix *data, int device, 
 }
 
 /* ======================================================================== */
+/* simplex_mesh_device: imported triangulations on one device or a group     */
+/* ======================================================================== */
+struct simplex_mesh_device {
+  gsl_sinterp_hip_ctx *ctx;        /* member 0 */
+  int n_tri, n_points, G, convex, n_members;
+  double geom[8];                  /* shift, scale, bounding box */
+  void *m_records[SINTERP_MAX_DEVICES], *m_leaftab[SINTERP_MAX_DEVICES];
+  int *m_tri[SINTERP_MAX_DEVICES], *m_seed[SINTERP_MAX_DEVICES];
+  shard_set ss;                    /* n_members > 1: ss.grp owns the contexts */
+  chunk_set cs;                    /* n_members == 1: pipelined host batches */
+  int response_bound;
+};
+
+gsl_sinterp_hip_ctx *simplex_mesh_device_ctx(simplex_mesh_device *dev) { return dev ? dev->ctx : NULL; }
+int simplex_mesh_device_n_devices(const simplex_mesh_device *dev) { return dev ? dev->n_members : 0; }
+
+static gsl_sinterp_hip_ctx *mesh_member_ctx(const simplex_mesh_device *dev, int r)
+{
+  return dev->ss.grp ? gsl_sinterp_hip_group_ctx(dev->ss.grp, r) : dev->ctx;
+}
+
+void simplex_mesh_device_free(simplex_mesh_device *dev)
+{
+  if (!dev) return;
+  for (int r = 0; r < dev->n_members; r++) {
+    gsl_sinterp_hip_ctx *c = mesh_member_ctx(dev, r);
+    if (!c) continue;
+    gsl_sinterp_hip_free(c, dev->m_records[r]); gsl_sinterp_hip_free(c, dev->m_leaftab[r]);
+    gsl_sinterp_hip_free(c, dev->m_tri[r]); gsl_sinterp_hip_free(c, dev->m_seed[r]);
+  }
+  if (dev->ss.grp) shard_set_release(&dev->ss);      /* destroys the members' contexts */
+  else if (dev->ctx) { chunk_set_release(&dev->cs, dev->ctx); gsl_sinterp_hip_ctx_destroy(dev->ctx); }
+  free(dev);
+}
+
+simplex_mesh_device *simplex_mesh_device_alloc_multi(const simplex_mesh *mesh, const int *devices, int n_devices)
+{
+  if (!mesh || !devices) GSL_ERROR_NULL("simplex_mesh_device_alloc: null argument", GSL_EFAULT);
+  if (n_devices < 1 || n_devices > SINTERP_MAX_DEVICES) GSL_ERROR_NULL("simplex_mesh_device_alloc: bad device list", GSL_EINVAL);
+  simplex_mesh_device *dev = (simplex_mesh_device *)calloc(1, sizeof *dev);
+  if (!dev) GSL_ERROR_NULL("simplex_mesh_device_alloc: out of memory", GSL_ENOMEM);
+  const size_t nt = simplex_mesh_n_triangles(mesh), np = simplex_mesh_n_points(mesh);
+  dev->n_tri = (int)nt; dev->n_points = (int)np; dev->convex = simplex_mesh_convex(mesh); dev->n_members = n_devices;
+  /* about two triangles per seed cell */
+  int G = (int)ceil(sqrt((double)nt / 2.0));
+  dev->G = G < 1 ? 1 : (G > 2048 ? 2048 : G);
+  simplex_mesh_geometry(mesh, dev->geom, dev->geom + 2);
+  simplex_mesh_bbox(mesh, dev->geom + 4, dev->geom + 6);
+  if (n_devices > 1) {
+    if (gsl_sinterp_hip_group_create(&dev->ss.grp, devices, n_devices) != GSL_SUCCESS) {
+      free(dev);
+      GSL_ERROR_NULL("simplex_mesh_device_alloc: cannot create the device group (GPU path has no CPU fallback)", GSL_EFAILED);
+    }
+    dev->ss.n = n_devices;
+    dev->ctx = gsl_sinterp_hip_group_ctx(dev->ss.grp, 0);
+  } else if (gsl_sinterp_hip_ctx_create(&dev->ctx, devices[0], NULL) != GSL_SUCCESS) {
+    free(dev);
+    GSL_ERROR_NULL("simplex_mesh_device_alloc: no usable HIP device (GPU path has no CPU fallback)", GSL_EFAILED);
+  }
+  const size_t tb = 3 * nt * sizeof(int), pb = 2 * np * sizeof(double);
+  int *d_nbr[SINTERP_MAX_DEVICES] = {0};
+  double *d_pts[SINTERP_MAX_DEVICES] = {0};
+  int st = GSL_SUCCESS;
+  for (int r = 0; r < n_devices && !st; r++) {
+    gsl_sinterp_hip_ctx *c = mesh_member_ctx(dev, r);
+    st = gsl_sinterp_hip_malloc(c, (void **)&dev->m_tri[r], tb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_nbr[r], tb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&d_pts[r], pb);
+    if (!st) st = gsl_sinterp_hip_malloc(c, &dev->m_records[r], nt * GSL_SINTERP_TREE_RECORD_BYTES);
+    if (!st) st = gsl_sinterp_hip_malloc(c, &dev->m_leaftab[r], nt * GSL_SINTERP_TREE_LEAFTAB_BYTES);
+    if (!st) st = gsl_sinterp_hip_malloc(c, (void **)&dev->m_seed[r], 2 * (size_t)dev->G * dev->G * sizeof(int));
+  }
+  if (!st) st = gsl_sinterp_hip_h2d(dev->ctx, dev->m_tri[0], simplex_mesh_triangles(mesh), tb);
+  if (!st) st = gsl_sinterp_hip_h2d(dev->ctx, d_nbr[0], simplex_mesh_neighbours(mesh), tb);
+  if (!st) st = gsl_sinterp_hip_h2d(dev->ctx, d_pts[0], simplex_mesh_points(mesh), pb);
+  if (!st && dev->ss.grp) {                             /* model replication: the only collective of the path */
+    st = gsl_sinterp_hip_group_broadcast(dev->ss.grp, (void *const *)dev->m_tri, tb);
+    if (!st) st = gsl_sinterp_hip_group_broadcast(dev->ss.grp, (void *const *)d_nbr, tb);
+    if (!st) st = gsl_sinterp_hip_group_broadcast(dev->ss.grp, (void *const *)d_pts, pb);
+  }
+  for (int r = 0; r < n_devices && !st; r++)            /* every member packs its own records and seed grid */
+    st = gsl_sinterp_hip_mesh_pack(mesh_member_ctx(dev, r), dev->n_tri, dev->m_tri[r], d_nbr[r], dev->n_points, d_pts[r], dev->geom, dev->G,
+                                   dev->m_records[r], dev->m_seed[r]);
+  for (int r = 0; r < n_devices; r++) {
+    gsl_sinterp_hip_ctx *c = mesh_member_ctx(dev, r);
+    int s2 = gsl_sinterp_hip_sync(c);
+    if (!st) st = s2;
+    gsl_sinterp_hip_free(c, d_nbr[r]); gsl_sinterp_hip_free(c, d_pts[r]);
+  }
+  if (st != GSL_SUCCESS) {
+    gsl_error(gsl_sinterp_hip_last_error(dev->ctx), __FILE__, __LINE__, st);
+    simplex_mesh_device_free(dev);
+    return NULL;
+  }
+  return dev;
+}
+
+simplex_mesh_device *simplex_mesh_device_alloc(const simplex_mesh *mesh, int device)
+{
+  return simplex_mesh_device_alloc_multi(mesh, &device, 1);
+}
+
+int simplex_mesh_device_set_response(simplex_mesh_device *dev, const gsl_vector *response)
+{
+  if (!dev || !response) GSL_ERROR("simplex_mesh_device_set_response: null argument", GSL_EFAULT);
+  if (response->size < (size_t)dev->n_points) GSL_ERROR("simplex_mesh_device_set_response: response shorter than the point set", GSL_EBADLEN);
+  const size_t np = (size_t)dev->n_points, rb = np * sizeof(double);
+  double *h = (double *)malloc(rb), *d_r[SINTERP_MAX_DEVICES] = {0};
+  if (!h) GSL_ERROR("simplex_mesh_device_set_response: out of memory", GSL_ENOMEM);
+  for (size_t i = 0; i < np; i++) h[i] = response->data[i * response->stride];
+  int st = GSL_SUCCESS;
+  for (int r = 0; r < dev->n_members && !st; r++) st = gsl_sinterp_hip_malloc(mesh_member_ctx(dev, r), (void **)&d_r[r], rb);
+  if (!st) st = gsl_sinterp_hip_h2d(dev->ctx, d_r[0], h, rb);
+  if (!st && dev->ss.grp) st = gsl_sinterp_hip_group_broadcast(dev->ss.grp, (void *const *)d_r, rb);
+  for (int r = 0; r < dev->n_members && !st; r++)
+    st = gsl_sinterp_hip_tree_bind(mesh_member_ctx(dev, r), dev->n_tri, dev->m_tri[r], dev->n_points, d_r[r], dev->m_leaftab[r]);
+  for (int r = 0; r < dev->n_members; r++) {
+    gsl_sinterp_hip_ctx *c = mesh_member_ctx(dev, r);
+    int s2 = gsl_sinterp_hip_sync(c);
+    if (!st) st = s2;
+    gsl_sinterp_hip_free(c, d_r[r]);
+  }
+  free(h);
+  if (st) GSL_ERROR(gsl_sinterp_hip_last_error(dev->ctx), st);
+  dev->response_bound = 1;
+  return GSL_SUCCESS;
+}
+
+int simplex_mesh_device_eval_resident(simplex_mesh_device *dev, const double *d_targets, size_t m, size_t ttda,
+                                      double *d_values, int *d_triangle)
+{
+  if (!dev) GSL_ERROR("simplex_mesh_device_eval_resident: null device mirror", GSL_EFAULT);
+  if (!dev->response_bound) GSL_ERROR("simplex_mesh_device_eval_resident: no response bound", GSL_EINVAL);
+  /* resident buffers live on ONE device: member 0 evaluates them */
+  int st = gsl_sinterp_hip_mesh_eval(dev->ctx, dev->n_tri, dev->m_records[0], dev->m_leaftab[0], dev->m_seed[0], dev->G, dev->geom, dev->convex,
+                                     d_targets, m, ttda, d_values, d_triangle, NULL);
+  if (st) GSL_ERROR(gsl_sinterp_hip_last_error(dev->ctx), st);
+  return GSL_SUCCESS;
+}
+
+static int mesh_shard_eval(void *state, int member, const double *d_y, size_t m, double *d_s, int *d_leaf)
+{
+  simplex_mesh_device *dev = (simplex_mesh_device *)state;
+  return gsl_sinterp_hip_mesh_eval(mesh_member_ctx(dev, member), dev->n_tri, dev->m_records[member], dev->m_leaftab[member], dev->m_seed[member],
+                                   dev->G, dev->geom, dev->convex, d_y, m, 2, d_s, d_leaf, (long long *)NULL);
+}
+static int mesh_chunk_eval(void *state, const double *d_y, size_t m, double *d_s, int *d_leaf) { return mesh_shard_eval(state, 0, d_y, m, d_s, d_leaf); }
+
+int simplex_mesh_device_eval_many(simplex_mesh_device *dev, const gsl_matrix *targets, gsl_vector *values, int *triangle)
+{
+  if (!dev || !targets || !values) GSL_ERROR("simplex_mesh_device_eval_many: null argument", GSL_EFAULT);
+  if (!dev->response_bound) GSL_ERROR("simplex_mesh_device_eval_many: no response bound", GSL_EINVAL);
+  if (targets->size2 != 2) GSL_ERROR("simplex_mesh_device_eval_many: targets must be M x 2", GSL_EBADLEN);
+  const size_t m = targets->size1;
+  if (values->size != m) GSL_ERROR("simplex_mesh_device_eval_many: values length must equal target rows", GSL_EBADLEN);
+  if (m == 0) return GSL_SUCCESS;
+  size_t outside_n = 0;
+  int st = dev->ss.grp ? shard_eval_many(&dev->ss, 2, targets, values, triangle, &mesh_shard_eval, dev, 1, &outside_n)
+                       : chunk_eval_many(&dev->cs, dev->ctx, 2, targets, values, triangle, &mesh_chunk_eval, dev, 1, &outside_n);
+  if (st != GSL_SUCCESS) GSL_ERROR("simplex_mesh_device_eval_many: evaluation failed", st);
+  if (outside_n) GSL_ERROR("simplex_mesh_device_eval_many: target(s) outside the triangulation", GSL_EDOM);
+  return GSL_SUCCESS;
+}
+
+/* ======================================================================== */
 /* RBF types                                                                 */
 /* ======================================================================== */
 typedef struct {
@@ -911,12 +1077,90 @@ static int simplex_eval_resident(const gsl_sinterp *interp, const double *d_y, s
 }
 
 /* ======================================================================== */
+/* imported triangulation type (README:28-31: QHull / CGAL meshes)           */
+/* ======================================================================== */
+typedef struct {
+  size_t n;
+  int *tri, *nbr;            /* the caller's triangulation (gsl_sinterp_set_triangulation), copied */
+  size_t n_tri;
+  simplex_mesh *mesh;
+  simplex_mesh_device *dev;
+  gsl_matrix *x;             /* private copies (checkpoints) */
+  gsl_vector *f;
+} mesh_state;
+
+static void *mesh_type_alloc(size_t dim, size_t size)
+{
+  if (dim != 2) return NULL;
+  mesh_state *st = (mesh_state *)calloc(1, sizeof *st);
+  if (st) st->n = size;
+  return st;
+}
+
+static void mesh_type_free(void *vstate)
+{
+  mesh_state *st = (mesh_state *)vstate;
+  if (!st) return;
+  simplex_mesh_device_free(st->dev);
+  simplex_mesh_free(st->mesh);
+  gsl_matrix_free(st->x);
+  gsl_vector_free(st->f);
+  free(st->tri); free(st->nbr);
+  free(st);
+}
+
+static int mesh_type_mirror(gsl_sinterp *interp, mesh_state *st)
+{
+  simplex_mesh_device_free(st->dev);
+  st->dev = interp->n_devices > 1 ? simplex_mesh_device_alloc_multi(st->mesh, interp->devices, interp->n_devices)
+                                  : simplex_mesh_device_alloc(st->mesh, interp->device);
+  if (!st->dev) return GSL_EFAILED;
+  return simplex_mesh_device_set_response(st->dev, st->f);
+}
+
+static int mesh_type_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *f)
+{
+  mesh_state *st = (mesh_state *)interp->state;
+  if (!st->tri) GSL_ERROR("gsl_sinterp_init: no triangulation set (gsl_sinterp_set_triangulation)", GSL_EINVAL);
+  simplex_mesh_device_free(st->dev); st->dev = NULL;
+  simplex_mesh_free(st->mesh); st->mesh = NULL;
+  gsl_matrix_free(st->x); gsl_vector_free(st->f);
+  st->x = gsl_matrix_alloc(st->n, 2);
+  st->f = gsl_vector_alloc(st->n);
+  if (!st->x || !st->f) return GSL_ENOMEM;
+  for (size_t i = 0; i < st->n; i++) {
+    gsl_matrix_set(st->x, i, 0, x->data[i * x->tda]);
+    gsl_matrix_set(st->x, i, 1, x->data[i * x->tda + 1]);
+    gsl_vector_set(st->f, i, gsl_vector_get(f, i));
+  }
+  st->mesh = simplex_mesh_import(st->x, st->tri, st->nbr, st->n_tri);
+  if (!st->mesh) return GSL_EINVAL;
+  return mesh_type_mirror(interp, st);
+}
+
+static int mesh_type_eval_many(const gsl_sinterp *interp, const gsl_matrix *y, gsl_vector *s, int *leaf)
+{
+  const mesh_state *st = (const mesh_state *)interp->state;
+  if (!st->dev) GSL_ERROR("gsl_sinterp_eval_many: interpolant not initialised", GSL_EINVAL);
+  return simplex_mesh_device_eval_many(st->dev, y, s, leaf);
+}
+
+static int mesh_type_eval_resident(const gsl_sinterp *interp, const double *d_y, size_t m, size_t ytda, double *d_s, int *d_leaf)
+{
+  const mesh_state *st = (const mesh_state *)interp->state;
+  if (!st->dev) GSL_ERROR("gsl_sinterp_eval_resident: interpolant not initialised", GSL_EINVAL);
+  return simplex_mesh_device_eval_resident(st->dev, d_y, m, ytda, d_s, d_leaf);
+}
+
+/* ======================================================================== */
 /* type table + generic entry points                                         */
 /* ======================================================================== */
 static const gsl_sinterp_type gauss_type = {"rbf-gaussian", 1, &rbf_gauss_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
 static const gsl_sinterp_type tps_type = {"rbf-thin-plate-spline", 1, &rbf_tps_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
 static const gsl_sinterp_type simplex_type = {"linear-simplex", 3, &simplex_alloc, &simplex_init, &simplex_eval_many, &simplex_eval_resident, &simplex_free};
 static const gsl_sinterp_type wendland_type = {"rbf-wendland-c2", 1, &rbf_wendland_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
+static const gsl_sinterp_type mesh_type = {"linear-imported-triangulation", 3, &mesh_type_alloc, &mesh_type_init, &mesh_type_eval_many, &mesh_type_eval_resident, &mesh_type_free};
+const gsl_sinterp_type *gsl_sinterp_linear_mesh = &mesh_type;
 static const gsl_sinterp_type tps_affine_type = {"rbf-thin-plate-spline-affine", 3, &rbf_tps_affine_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
 const gsl_sinterp_type *gsl_sinterp_rbf_tps_affine = &tps_affine_type;
 static const gsl_sinterp_type krige_type = {"ordinary-kriging-gaussian", 1, &krige_alloc, &rbf_init, &rbf_eval_many, &rbf_eval_resident, &rbf_free};
@@ -1058,6 +1302,21 @@ int gsl_sinterp_rcond(const gsl_sinterp *interp, double *rcond)
 }
 
 int gsl_sinterp_route(const gsl_sinterp *interp) { return interp ? interp->route : 0; }
+
+int gsl_sinterp_set_triangulation(gsl_sinterp *interp, const int *triangles, const int *neighbours, size_t n_triangles)
+{
+  if (!interp || !triangles) GSL_ERROR("gsl_sinterp_set_triangulation: null argument", GSL_EFAULT);
+  if (interp->type != &mesh_type) GSL_ERROR("gsl_sinterp_set_triangulation: imported-triangulation interpolants only", GSL_EINVAL);
+  if (n_triangles < 1 || n_triangles > (size_t)INT_MAX / 3) GSL_ERROR("gsl_sinterp_set_triangulation: bad triangle count", GSL_EINVAL);
+  mesh_state *st = (mesh_state *)interp->state;
+  int *t = (int *)malloc(3 * n_triangles * sizeof(int)), *nb = neighbours ? (int *)malloc(3 * n_triangles * sizeof(int)) : NULL;
+  if (!t || (neighbours && !nb)) { free(t); free(nb); GSL_ERROR("gsl_sinterp_set_triangulation: out of memory", GSL_ENOMEM); }
+  memcpy(t, triangles, 3 * n_triangles * sizeof(int));
+  if (nb) memcpy(nb, neighbours, 3 * n_triangles * sizeof(int));
+  free(st->tri); free(st->nbr);
+  st->tri = t; st->nbr = nb; st->n_tri = n_triangles;
+  return GSL_SUCCESS;
+}
 
 int gsl_sinterp_set_tree_options(gsl_sinterp *interp, int init_flags, gsl_rng *rng)
 {
@@ -1217,7 +1476,7 @@ static const char INTERP_MAGIC[8] = {'G', 'S', 'L', 'S', 'I', 'N', 'T', '1'};
 
 static int type_id(const gsl_sinterp_type *T)
 {
-  return T == &gauss_type ? 0 : (T == &tps_type ? 1 : (T == &wendland_type ? 3 : (T == &krige_type ? 4 : (T == &tps_affine_type ? 5 : 2))));
+  return T == &gauss_type ? 0 : (T == &tps_type ? 1 : (T == &wendland_type ? 3 : (T == &krige_type ? 4 : (T == &tps_affine_type ? 5 : (T == &mesh_type ? 6 : 2)))));
 }
 
 int gsl_sinterp_fwrite(FILE *stream, const gsl_sinterp *interp)
@@ -1237,6 +1496,22 @@ int gsl_sinterp_fwrite(FILE *stream, const gsl_sinterp *interp)
     for (size_t i = 0; i < st->n; i++) {
       const double row[3] = {gsl_matrix_get(st->x, i, 0), gsl_matrix_get(st->x, i, 1), gsl_vector_get(st->f, i)};
       if (fwrite(row, sizeof(double), 3, stream) != 3) GSL_ERROR("fwrite failed", GSL_EFAILED);
+    }
+    return GSL_SUCCESS;
+  }
+  if (interp->type == &mesh_type) {
+    const mesh_state *st = (const mesh_state *)interp->state;
+    if (!st->dev || !st->mesh || !st->x || !st->f) GSL_ERROR("gsl_sinterp_fwrite: interpolant not initialised", GSL_EINVAL);
+    const double eps = 0.0;
+    const int64_t flags = 0;
+    if (fwrite(INTERP_MAGIC, 1, 8, stream) != 8 || fwrite(head, sizeof head[0], 3, stream) != 3 ||
+        fwrite(&eps, sizeof eps, 1, stream) != 1 || fwrite(&flags, sizeof flags, 1, stream) != 1)
+      GSL_ERROR("fwrite failed", GSL_EFAILED);
+    int s = simplex_mesh_fwrite(stream, st->mesh);
+    if (s) return s;
+    for (size_t i = 0; i < st->n; i++) {
+      const double fi = gsl_vector_get(st->f, i);
+      if (fwrite(&fi, sizeof fi, 1, stream) != 1) GSL_ERROR("fwrite failed", GSL_EFAILED);
     }
     return GSL_SUCCESS;
   }
@@ -1293,6 +1568,28 @@ int gsl_sinterp_fread(FILE *stream, gsl_sinterp *interp)
     st->tree = tree; st->x = x; st->f = f;
     interp->init_flags = (int)flags;
     return simplex_mirror(interp, st);                  /* upload + pack + bind: no triangulation */
+  }
+  if (interp->type == &mesh_type) {
+    mesh_state *st = (mesh_state *)interp->state;
+    simplex_mesh *mesh = simplex_mesh_fread(stream);
+    if (!mesh) return GSL_EFAILED;
+    if (simplex_mesh_n_points(mesh) != st->n) { simplex_mesh_free(mesh); GSL_ERROR("gsl_sinterp_fread: mesh / size mismatch", GSL_EBADLEN); }
+    gsl_matrix *x = gsl_matrix_alloc(st->n, 2);
+    gsl_vector *f = gsl_vector_alloc(st->n);
+    int ok = x && f;
+    for (size_t i = 0; ok && i < st->n; i++) {
+      double fi;
+      ok = fread(&fi, sizeof fi, 1, stream) == 1;
+      if (ok) {
+        gsl_vector_set(f, i, fi);
+        gsl_matrix_set(x, i, 0, simplex_mesh_points(mesh)[2 * i]); gsl_matrix_set(x, i, 1, simplex_mesh_points(mesh)[2 * i + 1]);
+      }
+    }
+    if (!ok) { simplex_mesh_free(mesh); gsl_matrix_free(x); gsl_vector_free(f); GSL_ERROR("fread failed", GSL_EFAILED); }
+    simplex_mesh_device_free(st->dev); st->dev = NULL;
+    simplex_mesh_free(st->mesh); gsl_matrix_free(st->x); gsl_vector_free(st->f);
+    st->mesh = mesh; st->x = x; st->f = f;
+    return mesh_type_mirror(interp, st);                /* upload + pack + bind: nothing is re-imported */
   }
   rbf_state *st = (rbf_state *)interp->state;
   const size_t cnt = st->n * (st->dim + 1);

@@ -219,7 +219,16 @@ void simplex_mesh_geometry(const simplex_mesh *mesh, double shift[2], double sca
    Delaunay triangulation); simplex_mesh_set_convex overrides, simplex_mesh_convex reads the current setting. */
 void simplex_mesh_set_convex(simplex_mesh *mesh, int convex);
 int simplex_mesh_convex(const simplex_mesh *mesh);
+const double *simplex_mesh_points(const simplex_mesh *mesh);    /* [2 n_points], packed rows */
+void simplex_mesh_bbox(const simplex_mesh *mesh, double lo[2], double hi[2]);
+/* binary checkpoint of a mesh (gsl_matrix_fwrite conventions); fread re-validates ids and neighbour links */
+int simplex_mesh_fwrite(FILE *stream, const simplex_mesh *mesh);
+simplex_mesh *simplex_mesh_fread(FILE *stream);
 simplex_mesh_device *simplex_mesh_device_alloc(const simplex_mesh *mesh, int device);
+/* the mirror replicated over a device group (one broadcast of the raw arrays, every member packs its own records and
+   seed grid); eval_many shards its targets like simplex_tree_device_alloc_multi's mirror */
+simplex_mesh_device *simplex_mesh_device_alloc_multi(const simplex_mesh *mesh, const int *devices, int n_devices);
+int simplex_mesh_device_n_devices(const simplex_mesh_device *dev);
 void simplex_mesh_device_free(simplex_mesh_device *dev);
 int simplex_mesh_device_set_response(simplex_mesh_device *dev, const gsl_vector *response);
 int simplex_mesh_device_eval_many(simplex_mesh_device *dev, const gsl_matrix *targets, gsl_vector *values, int *triangle);
@@ -269,6 +278,9 @@ extern const gsl_sinterp_type *gsl_sinterp_rbf_tps;
 extern const gsl_sinterp_type *gsl_sinterp_rbf_tps_affine;
 extern const gsl_sinterp_type *gsl_sinterp_rbf_wendland;    /* compactly supported C2 kernel (README:18-26 future list) */
 extern const gsl_sinterp_type *gsl_sinterp_linear_simplex;
+/* piecewise-linear interpolation over an IMPORTED triangulation (QHull / CGAL arrays, README:28-31 future list): set the
+   triangles with gsl_sinterp_set_triangulation before gsl_sinterp_init(x, f); `leaf` of eval_many = triangle index */
+extern const gsl_sinterp_type *gsl_sinterp_linear_mesh;
 /* ordinary kriging with a Gaussian covariance exp(-(eps h)^2) and an optional nugget (README:24 future list):
    s(y) = mu + sum_j w_j C(|y - x_j|) with [C + nugget I, 1; 1^T, 0] [w; mu] = [f; 0].  nugget = 0 interpolates the data,
    nugget > 0 smooths (s(x_i) = f_i - nugget w_i); far from the data s -> mu.  gsl_sinterp_set_shape sets eps. */
@@ -298,6 +310,9 @@ int gsl_sinterp_set_rcond(gsl_sinterp *interp, int want);
 int gsl_sinterp_rcond(const gsl_sinterp *interp, double *rcond);
 int gsl_sinterp_route(const gsl_sinterp *interp);
 int gsl_sinterp_set_tree_options(gsl_sinterp *interp, int init_flags, gsl_rng *rng);
+/* gsl_sinterp_linear_mesh: triangles [3 n] (vertex = row of x), neighbours [3 n] (opposite vertex k, -1 = boundary) or NULL
+   (derived by edge matching); copied, validated by the next gsl_sinterp_init */
+int gsl_sinterp_set_triangulation(gsl_sinterp *interp, const int *triangles, const int *neighbours, size_t n_triangles);
 int gsl_sinterp_init(gsl_sinterp *interp, const gsl_matrix *x, const gsl_vector *f);
 const char *gsl_sinterp_name(const gsl_sinterp *interp);
 unsigned int gsl_sinterp_min_size(const gsl_sinterp *interp);

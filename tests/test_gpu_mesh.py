@@ -148,3 +148,73 @@ def test_nonconvex_mesh_and_resident_buffers(pkg, orc):
         assert (first >= 0) == bool(inside[k])
         if first >= 0:
             assert orc.mesh_contains(x, shift, scale, tri[idx[k]], y[k])
+
+
+def test_mesh_facade_type_groups_and_checkpoint(pkg, orc, tmp_path):
+    """Round 4: imported triangulations behind the gsl_sinterp facade (gsl_sinterp_linear_mesh + gsl_sinterp_set_triangulation),
+    replicated over a device group ([0, 0, 0]: one broadcast of the raw arrays, every member packs its own records) and
+    checkpointed; the sorted-target route (>= 4096 targets, two-level from 2^18) returns the bits of the per-target route."""
+    from scipy.spatial import Delaunay
+    n, m = 4000, 300_000
+    x = orc.synth_centres(n, 2)
+    f = orc.synth_response(x)
+    y = orc.synth_targets(0, m, 2)
+    d = Delaunay(x)
+    tri = d.simplices.astype(np.int32)
+    mesh = pkg.SimplexMesh.from_arrays(x, tri, d.neighbors.astype(np.int32))
+    dev = mesh.device_alloc(0)
+    assert dev.set_response(f) == 0
+    st0, v0, t0 = dev.eval_many(y)
+    small = [dev.eval_many(np.ascontiguousarray(y[i:i + 3000])) for i in range(0, 30000, 3000)]     # < 4096: unsorted route
+    assert all(s[0] in (0, pkg.GSL_EDOM) for s in small)
+    assert np.array_equal(np.concatenate([s[1] for s in small]).view(np.uint64), v0[:30000].view(np.uint64))
+    assert np.array_equal(np.concatenate([s[2] for s in small]), t0[:30000])
+    grp = mesh.device_alloc_multi([0, 0, 0])
+    assert grp.n_devices() == 3 and grp.set_response(f) == 0
+    st1, v1, t1 = grp.eval_many(y)
+    assert st1 == st0 and np.array_equal(v1.view(np.uint64), v0.view(np.uint64)) and np.array_equal(t1, t0)
+    # the facade type
+    s = pkg.Sinterp("linear_mesh", 2, n, 0)
+    assert s.name() == "linear-imported-triangulation"
+    assert s.init(x, f) == pkg.GSL_EINVAL                      # no triangulation yet
+    assert s.set_triangulation(tri) == 0 and s.init(x, f) == 0
+    st2, v2, t2 = s.eval_many(y, want_leaf=True)
+    assert st2 == st0 and np.array_equal(v2.view(np.uint64), v0.view(np.uint64)) and np.array_equal(t2, t0)
+    path = tmp_path / "mesh_interp.bin"
+    assert s.fwrite(path) == 0
+    r = pkg.Sinterp("linear_mesh", 2, n, 0)
+    assert r.set_device_list([0, 0]) == 0 and r.fread(path) == 0
+    st3, v3, t3 = r.eval_many(y, want_leaf=True)
+    assert st3 == st0 and np.array_equal(v3.view(np.uint64), v0.view(np.uint64)) and np.array_equal(t3, t0)
+    assert pkg.Sinterp("linear_simplex", 2, n, 0).fread(path) == pkg.capi.GSL_EBADLEN
+
+
+def test_cyclic_non_delaunay_import_has_bounded_cost(pkg, orc):
+    """A valid but badly shaped (non-Delaunay) triangulation can make the straight walk circle; such targets leave the walk
+    after 64 + 4 G steps and are resolved by the exhaustive scan.  The cost must stay bounded: a fan of long slivers
+    around one hub, 20 000 targets, finishes in well under a second and agrees with the exhaustive oracle search."""
+    import time
+    k = 720
+    ang = np.linspace(0.0, 2.0 * np.pi, k, endpoint=False)
+    ring = np.stack([np.cos(ang), np.sin(ang)], axis=1) * (1.0 + 0.3 * np.sin(7 * ang))[:, None]
+    x = np.vstack([[0.0, 0.0], ring])
+    tri = np.array([[0, 1 + i, 1 + (i + 1) % k] for i in range(k)], dtype=np.int32)       # slivers around the hub
+    f = 1.0 + 2.0 * x[:, 0] - x[:, 1]
+    mesh = pkg.SimplexMesh.from_arrays(x, tri)
+    assert not mesh.convex()
+    dev = mesh.device_alloc(0)
+    assert dev.set_response(f) == 0
+    rng = np.random.default_rng(5)
+    y = rng.uniform(-0.6, 0.6, size=(20000, 2))
+    dev.eval_many(y)                                             # warm-up (allocations)
+    t0 = time.perf_counter()
+    st, v, t = dev.eval_many(y)
+    dt = time.perf_counter() - t0
+    assert st in (0, pkg.GSL_EDOM) and dt < 1.0, dt
+    inside = t >= 0
+    assert inside.mean() > 0.95
+    assert np.abs(v[inside] - (1.0 + 2.0 * y[inside, 0] - y[inside, 1])).max() < 1e-12
+    shift, scale = mesh.geometry()
+    for q in range(0, 20000, 997):
+        first, cnt = orc.mesh_locate(x, shift, scale, tri, y[q])
+        assert (first >= 0) == bool(inside[q])

@@ -82,3 +82,44 @@ def test_export_of_a_tree_keeps_leaves_and_links(pkg, orc):
     assert mesh.n_triangles <= 2 * n - 5
     shift, scale = mesh.geometry()
     assert np.array_equal(np.concatenate([shift, scale]), t.geom()[6:10])
+
+
+def test_mesh_checkpoint_round_trip_and_validation(pkg, orc, tmp_path):
+    """simplex_mesh_fwrite / _fread: arrays, geometry and the convexity flag come back; truncated, foreign and corrupted
+    files (vertex id out of range, one-sided neighbour link) are refused, not crashed on."""
+    x = orc.synth_centres(300, 2)
+    _, tri, nbr = qhull(x)
+    m = pkg.SimplexMesh.from_arrays(x, tri, nbr)
+    path = tmp_path / "mesh.bin"
+    assert m.fwrite(path) == 0
+    r = pkg.SimplexMesh.fread(path)
+    assert r is not None and r.n_triangles == m.n_triangles and r.convex() == m.convex()
+    assert np.array_equal(r.triangles(), tri) and np.array_equal(r.neighbours(), nbr)
+    sa, ca = m.geometry(); sb, cb = r.geometry()
+    assert np.array_equal(sa, sb) and np.array_equal(ca, cb)
+    blob = path.read_bytes()
+
+    def load(b):
+        p = tmp_path / "bad.bin"
+        p.write_bytes(bytes(b))
+        try:
+            return pkg.SimplexMesh.fread(p)
+        except pkg.capi.GslError:
+            return None
+    assert load(blob[: len(blob) // 2]) is None and load(b"nonsense" * 8) is None
+    bad = bytearray(blob)
+    off_tri = 8 + 32
+    bad[off_tri:off_tri + 4] = (10 ** 6).to_bytes(4, "little")                    # vertex id out of range
+    assert load(bad) is None
+    bad = bytearray(blob)
+    off_nbr = off_tri + 12 * len(tri)
+    first = int.from_bytes(blob[off_nbr:off_nbr + 4], "little", signed=True)
+    other = (first + 1) % len(tri) if first >= 0 else 0
+    bad[off_nbr:off_nbr + 4] = other.to_bytes(4, "little", signed=True)            # a link its neighbour does not answer
+    assert load(bad) is None
+    t = pkg.SimplexTree(2, 300)
+    assert t.init(x, flags=0, rng=pkg.capi.Rng(0)) == 0
+    e = pkg.SimplexMesh.from_tree(t)
+    assert e.fwrite(tmp_path / "exported.bin") == 0
+    e2 = pkg.SimplexMesh.fread(tmp_path / "exported.bin")
+    assert np.array_equal(e2.tree_nodes(), e.tree_nodes()) and np.array_equal(e2.triangles(), e.triangles())
