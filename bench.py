@@ -38,7 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix = vector peak; 256 CU x 128 flop/clk x 2.4 GHz
 VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9   # fp64 VALU issue: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz lane-instructions/s
-PMC_ROUND = "r03"            # committed rocprofv3 --pmc passes the static counter figures are read from
+PMC_ROUND = "r04"            # committed rocprofv3 --pmc passes the static counter figures are read from
 
 CONFIGS = {
     # name: (kind, dim, n_centres, m_targets, sharding)   sharding: per_gpu = weak, total = strong

@@ -229,6 +229,7 @@ SIGNATURES = {
     "gsl_sinterp_hip_pipe_mark": (_i, [_vp, _pi]),
     "gsl_sinterp_hip_pipe_download": (_i, [_vp, _i, _vp, _vp, _sz]),
     "gsl_sinterp_hip_pipe_sync": (_i, [_vp]),
+    "gsl_sinterp_hip_bary_last_queue": (_i, [_vp, C.POINTER(C.c_uint), _pi]),
     "gsl_sinterp_hip_count_negative": (_i, [_vp, _vp, _sz, C.POINTER(C.c_longlong)]),
     "gsl_sinterp_hip_rbf_solve_affine": (_i, [_vp, _i, _d, _vp, _sz, _i, _sz, _vp, _sz, _vp, _pd, _pi]),
     "gsl_sinterp_hip_rbf_eval_affine": (_i, [_vp, _i, _d, _pd, _vp, _sz, _i, _sz, _vp, _vp, _sz, _sz, _vp, C.c_uint64]),

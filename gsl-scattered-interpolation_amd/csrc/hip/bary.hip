@@ -807,6 +807,11 @@ bary_eval_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__
   }
 }
 
+/* builds the locator data of "Certified leaf walk" for the records just packed; leaves ctx->lw_rec NULL when the tree
+   cannot be certified (a sub-DAG too deep / wide for the push kernel's stack, non-finite constants) */
+static int lw_build(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type, const int *d_pidx, const int *d_links, int n_points,
+                    const double *d_points, const Geom &g, const NodeRec *d_records);
+
 /* ------------------------------------------------------------------------ */
 extern "C" int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type, const int *d_pidx,
                                          const int *d_links, int n_points, const double *d_points,
@@ -870,6 +875,13 @@ extern "C" int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
     LAUNCH_CHECK(ctx);
     ctx->jump_rec = d_records; ctx->jump_nodes = n_nodes; ctx->jump_G = G;
   }
+  /* certified leaf walk: seed grid + per-leaf line lists + margin constants (see "Certified leaf walk") */
+  ctx->lw_rec = NULL;
+  static const bool no_lw = getenv("GSL_SINTERP_NO_LEAFWALK") && getenv("GSL_SINTERP_NO_LEAFWALK")[0] == '1';
+  if (!no_lw && n_nodes >= 2048 && n_points >= 3 && d_points) {
+    int st = lw_build(ctx, n_nodes, d_type, d_pidx, d_links, n_points, d_points, g, (const NodeRec *)d_records);
+    if (st) return st;
+  }
   return ST_SUCCESS;
 }
 
@@ -884,6 +896,356 @@ extern "C" int gsl_sinterp_hip_tree_bind(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   hipLaunchKernelGGL(tree_bind_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, n_nodes, d_pidx,
                      n_points, d_response, (LeafRec *)d_leaftab);
   LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+/* ======================================================================== */
+/* Certified leaf walk (round 4; SURVEY.md 8(f) row 1 as written: grid seed + walk over the leaves' `links` adjacency,
+   verified with the reference's containment arithmetic, the DAG walk inside an eps-band of any edge).
+
+   The reference's find_leaf descends the history DAG with a floating-point closed test at every node
+   (linear_simplex.c:352-402).  Let p be a target and L a FINAL leaf whose own test accepts p.  If every test the descent
+   can meet agrees with geometry -- i.e. p keeps a distance from every edge of every DAG node that exceeds the rounding
+   error of that node's test -- then at every node exactly one child contains p, the first-containing-child rule picks it,
+   and the descent ends in the one leaf that contains p: L, with the persistent coordinates the test at L computes.
+   Which edges can come near p?  A segment that does not meet the interior of L is at least dist(p, boundary of L) away
+   from p, so only (i) L's own edges and (ii) the HISTORIC edges that cross L matter.  An edge disappears from a
+   Delaunay history only through a flip (edge_flip.c:117-207): the flipped-away edge e of node A is the edge of A that
+   neither child keeps, and it runs through both children -- and through whatever later replaces them.  tree_pack
+   therefore pushes every such e down the sub-DAG of A's children (lw_push_kernel: a conservative segment / triangle
+   clip test in barycentric coordinates with 1e-7 slack, depth-first with a small visited set) and leaves, per final
+   leaf, the LINES of its three edges and of every historic edge that reaches it (Euclidean normal form in raw
+   coordinates, CSR lists).  The rounding error of a node's test, in the same Euclidean terms, is at most
+   alpha_N (|d0| + |d1|) h_N (alpha_N: the per-node constant of the certified walk below, 64u x the forward error
+   constant; h_N the largest height of the triangle), so with K = max_N alpha_N h_N, R = max_N |x0_N - c|_1:
+        | line(p) | > E(p) = 2 K (|p - c|_1 + R)   for every line of L's list     ==>     find_leaf(p) = L.
+   A target that fails the margin, leaves the walk without a leaf (outside the cage, NaN, a step bound), or meets
+   anything non-finite is queued for bary_eval_kernel, the reference's arithmetic at every step.  So leaves and values
+   stay the reference's bit for bit; what changes is the cost: a grid seed + a few neighbour steps (one 64-byte record
+   each, shared by the wave because the targets arrive in cell order) instead of a 6.5-step descent with two records per
+   step.  GSL_SINTERP_NO_LEAFWALK=1 selects the certified DAG walk of round 2. */
+__global__ void mesh_seed_init_kernel(int *__restrict__ seed, size_t cells);
+__global__ void mesh_seed_fill_kernel(const int *__restrict__ seed_in, int *__restrict__ seed_out, int G);
+#define LW_STACK 96
+#define LW_SEEN 48
+#define LW_DELTA 1e-7
+#define LW_MAX_STEPS 192
+
+__device__ __forceinline__ void lw_vertex(int id, const double *__restrict__ points, int n_points, const Geom &g, double &x, double &y)
+{
+  if (id < 0) { x = g.seed[2 * (-id - 1)]; y = g.seed[2 * (-id - 1) + 1]; }
+  else if (id < n_points) { x = points[2 * id]; y = points[2 * id + 1]; }
+  else { x = y = 0.0; }
+}
+
+__device__ __forceinline__ void atomic_max_nonneg(unsigned long long *dst, double v)
+{
+  if (!(v >= 0.0)) v = INFINITY;                        /* NaN: poison the maximum, the fast path is then never taken */
+  atomicMax(dst, (unsigned long long)__double_as_longlong(v));
+}
+
+/* consts[0] = K bits, [1] = R bits, [2] = overflow flag, [3] = (unused) */
+__global__ void __launch_bounds__(256)
+lw_bound_kernel(int n_nodes, const NodeRec *__restrict__ rec, double s0, double s1, double c0, double c1,
+                unsigned long long *__restrict__ consts)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  double kn = 0.0, rn = 0.0;
+  if (k < n_nodes) {
+    const NodeRec r = rec[k];
+    rn = fabs(r.x0 - c0) + fabs(r.x1 - c1);
+    if (!META_SINGULAR(r.meta)) {                       /* a singular node is rejected without a solve: no rounding involved */
+      const bool sw = META_SWAPPED(r.meta);
+      const double sa = sw ? s1 : s0, sb = sw ? s0 : s1;
+      const double m1a = -(r.l10 * sa) / r.u11, m1b = sb / r.u11;
+      const double m0a = (sa - r.u01 * m1a) / r.u00, m0b = -(r.u01 * m1b) / r.u00;
+      const double A1a = fabs(r.l10) * sa / fabs(r.u11), A1b = sb / fabs(r.u11);
+      const double A0a = (sa + fabs(r.u01) * A1a) / fabs(r.u00), A0b = fabs(r.u01) * A1b / fabs(r.u00);
+      const double alpha = fmax(A0a + A1a, A0b + A1b) * (0x1p-47 * (1.0 + 0x1p-10));    /* as walk_pack_kernel */
+      double g = 1.0;
+      const double v[6] = {r.l10, r.u01, r.u11, r.u00, sa, sb};
+#pragma unroll
+      for (int i = 0; i < 6; i++) { const double a = fabs(v[i]); g *= fmax(1.0, a); if (i >= 2) g *= fmax(1.0, 1.0 / a); }
+      /* heights: 1 / |gradient| of the three coordinates (raw coordinates) */
+      const double g0 = sqrt(m0a * m0a + m0b * m0b), g1 = sqrt(m1a * m1a + m1b * m1b);
+      const double g2 = sqrt((m0a + m1a) * (m0a + m1a) + (m0b + m1b) * (m0b + m1b));
+      const double hmax = 1.0 / fmin(g0, fmin(g1, g2));
+      const bool ok = sa > 0.0 && sb > 0.0 && g <= 0x1p200 && alpha < 1e30;
+      kn = ok ? alpha * hmax * (1.0 + 0x1p-10) : INFINITY;
+      if (!(kn == kn)) kn = INFINITY;
+    }
+  }
+  /* wave maximum, then one atomic per wave */
+  for (int off = 32; off > 0; off >>= 1) { kn = fmax(kn, __shfl_xor(kn, off)); rn = fmax(rn, __shfl_xor(rn, off)); }
+  if ((threadIdx.x & 63) == 0) { atomic_max_nonneg(&consts[0], kn); atomic_max_nonneg(&consts[1], rn); }
+}
+
+struct LwGrid { double lo0, lo1, w0, w1; int G; };
+__device__ __forceinline__ int lw_cell(const LwGrid &g, double y0, double y1)
+{
+  int ix = (int)((y0 - g.lo0) / g.w0), iy = (int)((y1 - g.lo1) / g.w1);
+  ix = ix < 0 ? 0 : (ix >= g.G ? g.G - 1 : ix);
+  iy = iy < 0 ? 0 : (iy >= g.G ? g.G - 1 : iy);
+  return iy * g.G + ix;
+}
+
+__global__ void lw_seed_kernel(int n_nodes, const int *__restrict__ type, const int *__restrict__ pidx, int n_points,
+                               const double *__restrict__ points, LwGrid g, int *__restrict__ seed)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_nodes || type[k] != 0) return;
+  const int a = pidx[3 * k], b = pidx[3 * k + 1], c = pidx[3 * k + 2];
+  if (a < 0 || b < 0 || c < 0 || a >= n_points || b >= n_points || c >= n_points) return;     /* cage leaves: reached by walking */
+  const double cx = (points[2 * a] + points[2 * b] + points[2 * c]) / 3.0, cy = (points[2 * a + 1] + points[2 * b + 1] + points[2 * c + 1]) / 3.0;
+  atomicMax(&seed[lw_cell(g, cx, cy)], k);
+}
+
+/* line through P, Q in Euclidean normal form (raw coordinates): a x + b y + c = signed distance */
+__device__ __forceinline__ void lw_line(double px, double py, double qx, double qy, double *__restrict__ out)
+{
+  const double dx = qx - px, dy = qy - py, len = sqrt(dx * dx + dy * dy);
+  const double a = dy / len, b = -dx / len;
+  out[0] = a; out[1] = b; out[2] = -(a * px + b * py);
+}
+
+/* does the segment P-Q come within LW_DELTA (barycentric) of the closed triangle of record r?  NaN / singular: yes */
+__device__ __forceinline__ bool lw_touches(const NodeRec &r, double px, double py, double qx, double qy, double s0, double s1)
+{
+  if (META_SINGULAR(r.meta)) return true;
+  double p0, p1, q0, q1;
+  solve_node(r, px, py, s0, s1, p0, p1);
+  solve_node(r, qx, qy, s0, s1, q0, q1);
+  const double cp[3] = {p0, p1, 1.0 - p0 - p1}, cq[3] = {q0, q1, 1.0 - q0 - q1};
+  double t0 = 0.0, t1 = 1.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (!(cp[i] == cp[i] && cq[i] == cq[i])) return true;
+    /* c(t) = cp + t (cq - cp) >= -delta */
+    const double a = cp[i] + LW_DELTA, d = cq[i] - cp[i];
+    if (d == 0.0) { if (a < 0.0) return false; continue; }
+    const double tc = -a / d;
+    if (d > 0.0) t0 = fmax(t0, tc); else t1 = fmin(t1, tc);
+  }
+  return t0 <= t1 + 1e-12;
+}
+
+/* pass 0: cnt[leaf] += 1 for every (historic edge, leaf) incidence; pass 1: the lines themselves behind the leaf's own
+   three (off[leaf] + 3 + slot).  One thread per internal node A; its flipped-away edges = edges of A that no child keeps. */
+__global__ void __launch_bounds__(128)
+lw_push_kernel(int n_nodes, const int *__restrict__ type, const int *__restrict__ pidx, const int *__restrict__ links, int n_points,
+               const double *__restrict__ points, Geom g, const NodeRec *__restrict__ rec, int pass, unsigned *__restrict__ cnt,
+               const unsigned *__restrict__ off, double *__restrict__ lines, unsigned long long *__restrict__ consts)
+{
+  const int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= n_nodes) return;
+  const int t = type[A];
+  if (t == 0) {
+    if (pass == 1) {                                    /* the leaf's own edges open its list */
+      double vx[3], vy[3];
+      for (int i = 0; i < 3; i++) lw_vertex(pidx[3 * A + i], points, n_points, g, vx[i], vy[i]);
+      for (int i = 0; i < 3; i++) lw_line(vx[(i + 1) % 3], vy[(i + 1) % 3], vx[(i + 2) % 3], vy[(i + 2) % 3], lines + 3 * ((size_t)off[A] + i));
+    }
+    return;
+  }
+  const int nch = t == 1 ? 3 : 2;
+  int ch[3];
+  for (int i = 0; i < 3; i++) ch[i] = i < nch ? links[3 * A + i] : 0;
+  /* a flip makes two nodes with the same children (linear_simplex / edge_flip: LINK(leaf, 2) = neighbor): one of them pushes */
+  if (t != 1) {
+    const int B = links[3 * A + 2];
+    if (B > 0 && B < n_nodes && B < A && type[B] == t && links[3 * B] == ch[0] && links[3 * B + 1] == ch[1] && links[3 * B + 2] == A) return;
+  }
+  const int va[3] = {pidx[3 * A], pidx[3 * A + 1], pidx[3 * A + 2]};
+  for (int e = 0; e < 3; e++) {
+    const int u = va[(e + 1) % 3], v = va[(e + 2) % 3];
+    bool kept = false;
+    for (int i = 0; i < nch && !kept; i++) {
+      const int c = ch[i];
+      if (!(c > 0 && c < n_nodes)) continue;
+      int hit = 0;
+      for (int q = 0; q < 3; q++) { const int w = pidx[3 * c + q]; hit += (w == u) + (w == v); }
+      kept = hit == 2;
+    }
+    if (kept) continue;
+    double px, py, qx, qy, ln[3];
+    lw_vertex(u, points, n_points, g, px, py);
+    lw_vertex(v, points, n_points, g, qx, qy);
+    lw_line(px, py, qx, qy, ln);
+    int stack[LW_STACK], seen[LW_SEEN], sp = 0, ns = 0;
+    for (int i = 0; i < nch; i++) if (ch[i] > 0 && ch[i] < n_nodes) stack[sp++] = ch[i];
+    while (sp > 0) {
+      const int y = stack[--sp];
+      bool dup = false;
+      for (int i = 0; i < ns; i++) dup = dup || seen[i] == y;
+      if (dup) continue;
+      if (ns >= LW_SEEN) { atomicExch(&consts[2], 1ULL); return; }
+      seen[ns++] = y;
+      const NodeRec r = rec[y];
+      if (!lw_touches(r, px, py, qx, qy, g.scale[0], g.scale[1])) continue;
+      if (META_TYPE(r.meta) == 0) {
+        const unsigned slot = atomicAdd(&cnt[y], 1u);
+        if (pass == 1) { double *o = lines + 3 * ((size_t)off[y] + 3 + slot); o[0] = ln[0]; o[1] = ln[1]; o[2] = ln[2]; }
+        continue;
+      }
+      const int nc = META_NCHILD(r.meta);
+      for (int i = 0; i < nc; i++) {
+        const int c = r.child[i];
+        if (!(c > 0 && c < n_nodes)) continue;
+        if (sp >= LW_STACK) { atomicExch(&consts[2], 1ULL); return; }
+        stack[sp++] = c;
+      }
+    }
+  }
+}
+
+__global__ void lw_cnt_init_kernel(int n_nodes, const int *__restrict__ type, unsigned *__restrict__ cnt, unsigned base)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k <= n_nodes) cnt[k] = (k < n_nodes && type[k] == 0) ? base : 0u;
+}
+__global__ void lw_cnt_zero_kernel(int n, unsigned *__restrict__ cnt)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) cnt[k] = 0u;
+}
+
+__device__ __forceinline__ void leaf_finish(const NodeRec &cur, const LeafRec *__restrict__ tab, int t, double c0, double c1, size_t k,
+                                            double *__restrict__ values, int *__restrict__ leaf_out, int packed)
+{
+  const LeafRec lr = tab[t];
+  double tot = 0, interp = 0;                                  /* linear_simplex.c:678-711 */
+  tot += c0;
+  if (lr.mask & 1) interp += c0 * lr.f[0];
+  tot += c1;
+  if (lr.mask & 2) interp += c1 * lr.f[1];
+  if (lr.mask & 4) interp += (1 - tot) * lr.f[2];
+  store_result(values, leaf_out, k, interp, t, packed);
+}
+
+/* one target per lane (cell order); todo_count / todo: the queue of the exact kernel */
+__global__ void __launch_bounds__(256)
+leafwalk_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, const int *__restrict__ seed, LwGrid g,
+                const unsigned *__restrict__ off, const double *__restrict__ lines, double K2, double R, double c0c, double c1c,
+                double s0, double s1, const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
+                int *__restrict__ leaf_out, unsigned *__restrict__ todo_count, int *__restrict__ todo, int packed)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
+  int found = -1;
+  double c0 = 0.0, c1 = 0.0;
+  NodeRec cur;
+  if (y0 == y0 && y1 == y1) {
+    int t = seed[lw_cell(g, y0, y1)], prev = -1;
+    for (int step = 0; step < LW_MAX_STEPS && t > 0 && t < n_nodes; step++) {
+      cur = load_rec(rec, t);
+      if (META_TYPE(cur.meta) != 0 || META_SINGULAR(cur.meta)) break;
+      solve_node(cur, y0, y1, s0, s1, c0, c1);
+      if (inside_unit(c0, c1)) { found = t; break; }
+      const double c2 = 1.0 - (c0 + c1);
+      if (!(c0 == c0 && c1 == c1 && c2 == c2)) break;
+      /* cross the edge opposite the most negative coordinate that has a neighbour */
+      const double v[3] = {c0, c1, c2};
+      int next = -1;
+      double best = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int nb = i == 0 ? cur.child[0] : (i == 1 ? cur.child[1] : cur.child[2]);
+        if (v[i] < best && nb > 0 && nb != prev) { best = v[i]; next = nb; }
+      }
+      if (next < 0) break;
+      prev = t;
+      t = next;
+    }
+  }
+  bool safe = found >= 0;
+  if (safe) {
+    const double E = K2 * (fabs(y0 - c0c) + fabs(y1 - c1c) + R);
+    const unsigned b = off[found], e = off[found + 1];
+    safe = E == E && E < INFINITY;
+    for (unsigned i = b; i < e && safe; i++) {
+      const double d = lines[3 * (size_t)i] * y0 + lines[3 * (size_t)i + 1] * y1 + lines[3 * (size_t)i + 2];
+      safe = fabs(d) > E;                                 /* NaN -> false */
+    }
+  }
+  if (safe) { leaf_finish(cur, tab, found, c0, c1, k, values, leaf_out, packed); return; }
+  const unsigned slot = atomicAdd(todo_count, 1u);
+  todo[slot] = (int)k;
+}
+
+static int lw_build(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type, const int *d_pidx, const int *d_links, int n_points,
+                    const double *d_points, const Geom &g, const NodeRec *d_records)
+{
+  /* seed grid: about two leaves per cell (a triangulation of n points has ~2n leaves; n_nodes ~ 9n) */
+  int Gs = 16;
+  while (Gs < 2048 && (double)Gs * Gs < (double)n_nodes / 9.0) Gs *= 2;
+  const size_t cells = (size_t)Gs * Gs, nrun = (size_t)n_nodes / 1024 + 4;
+  const size_t a_bytes = 64 + (2 * cells) * sizeof(int) + ((size_t)n_nodes + 1 + nrun) * sizeof(unsigned);
+  if (a_bytes > ctx->lw_a_bytes) {
+    if (ctx->d_lw_a) { HIP_OK(ctx, hipStreamSynchronize(ctx->stream)); HIP_OK(ctx, hipFree(ctx->d_lw_a)); ctx->d_lw_a = NULL; ctx->lw_a_bytes = 0; }
+    HIP_OK(ctx, hipMalloc(&ctx->d_lw_a, a_bytes));
+    ctx->lw_a_bytes = a_bytes;
+  }
+  unsigned long long *consts = (unsigned long long *)ctx->d_lw_a;
+  int *seed = (int *)((char *)ctx->d_lw_a + 64), *seed_raw = seed + cells;
+  unsigned *off = (unsigned *)(seed_raw + cells), *runsum = off + n_nodes + 1;
+  /* bounding box of the data (the jump table's keys when it was built, else computed here) */
+  unsigned long long hbox[4];
+  {
+    unsigned long long *d_box = (unsigned long long *)((char *)ctx->d_lw_a + 32);     /* bytes 32..63 of the header */
+    int st = sinterp_bbox_keys(ctx, d_points, (size_t)n_points, 2, 2, d_box);
+    if (st) return st;
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_OK(ctx, hipMemcpy(hbox, d_box, sizeof hbox, hipMemcpyDeviceToHost));
+  }
+  auto key = [](unsigned long long k) { unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k; double d; memcpy(&d, &u, sizeof d); return d; };
+  const double lo0 = key(hbox[0]), hi0 = key(hbox[1]), lo1 = key(hbox[2]), hi1 = key(hbox[3]);
+  if (!(hi0 > lo0 && hi1 > lo1)) return ST_SUCCESS;
+  LwGrid lg;
+  lg.lo0 = lo0; lg.lo1 = lo1; lg.w0 = (hi0 - lo0) / Gs; lg.w1 = (hi1 - lo1) / Gs; lg.G = Gs;
+  const double c0 = 0.5 * (lo0 + hi0), c1 = 0.5 * (lo1 + hi1);
+  HIP_OK(ctx, hipMemsetAsync(consts, 0, 32, ctx->stream));
+  const unsigned nb = (unsigned)((n_nodes + 255) / 256);
+  hipLaunchKernelGGL(lw_bound_kernel, dim3(nb), dim3(256), 0, ctx->stream, n_nodes, d_records, g.scale[0], g.scale[1], c0, c1, consts);
+  hipLaunchKernelGGL(mesh_seed_init_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, seed_raw, cells);
+  hipLaunchKernelGGL(lw_seed_kernel, dim3(nb), dim3(256), 0, ctx->stream, n_nodes, d_type, d_pidx, n_points, d_points, lg, seed_raw);
+  hipLaunchKernelGGL(mesh_seed_fill_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, (const int *)seed_raw, seed, Gs);
+  /* pass 0: list lengths (3 own edges per leaf + the historic edges that reach it), scan, pass 1: the lines */
+  hipLaunchKernelGGL(lw_cnt_init_kernel, dim3((unsigned)((n_nodes + 256) / 256)), dim3(256), 0, ctx->stream, n_nodes, d_type, off, 3u);
+  const unsigned pb = (unsigned)((n_nodes + 127) / 128);
+  hipLaunchKernelGGL(lw_push_kernel, dim3(pb), dim3(128), 0, ctx->stream, n_nodes, d_type, d_pidx, d_links, n_points, d_points, g, d_records,
+                     0, off, (const unsigned *)NULL, (double *)NULL, consts);
+  sinterp_scan_u32(ctx, off, (size_t)n_nodes, runsum);
+  LAUNCH_CHECK(ctx);
+  unsigned long long hc[4] = {0, 0, 0, 0};
+  unsigned total = 0;
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(hc, consts, 32, hipMemcpyDeviceToHost));
+  HIP_OK(ctx, hipMemcpy(&total, off + n_nodes, sizeof total, hipMemcpyDeviceToHost));
+  double K, R;
+  memcpy(&K, &hc[0], sizeof K); memcpy(&R, &hc[1], sizeof R);
+  if (hc[2] != 0 || !(K >= 0.0 && K < 1e-3) || !(R >= 0.0 && R < INFINITY) || total == 0) return ST_SUCCESS;   /* not certifiable: DAG walk */
+  const size_t l_bytes = (size_t)total * 3 * sizeof(double);
+  if (l_bytes > ctx->lw_lines_bytes) {
+    if (ctx->d_lw_lines) { HIP_OK(ctx, hipFree(ctx->d_lw_lines)); ctx->d_lw_lines = NULL; ctx->lw_lines_bytes = 0; }
+    HIP_OK(ctx, hipMalloc(&ctx->d_lw_lines, l_bytes));
+    ctx->lw_lines_bytes = l_bytes;
+  }
+  /* the fill pass re-counts into a scratch copy of the counters (the sort buffer) */
+  void *sb = NULL;
+  int st = sinterp_sortbuf2(ctx, ((size_t)n_nodes + 1) * sizeof(unsigned), &sb);
+  if (st) return st;
+  unsigned *fillcnt = (unsigned *)sb;
+  hipLaunchKernelGGL(lw_cnt_zero_kernel, dim3((unsigned)((n_nodes + 256) / 256)), dim3(256), 0, ctx->stream, n_nodes + 1, fillcnt);
+  hipLaunchKernelGGL(lw_push_kernel, dim3(pb), dim3(128), 0, ctx->stream, n_nodes, d_type, d_pidx, d_links, n_points, d_points, g, d_records,
+                     1, fillcnt, (const unsigned *)off, (double *)ctx->d_lw_lines, consts);
+  LAUNCH_CHECK(ctx);
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(hc, consts, 32, hipMemcpyDeviceToHost));
+  if (hc[2] != 0) return ST_SUCCESS;
+  ctx->lw_rec = d_records; ctx->lw_nodes = n_nodes; ctx->lw_Gs = Gs;
+  ctx->lw_K = K; ctx->lw_R = R; ctx->lw_c[0] = c0; ctx->lw_c[1] = c1;
+  ctx->lw_lo[0] = lo0; ctx->lw_lo[1] = lo1; ctx->lw_w[0] = lg.w0; ctx->lw_w[1] = lg.w1;
   return ST_SUCCESS;
 }
 
@@ -1011,6 +1373,58 @@ static int bary_eval_part(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_r
   return ST_SUCCESS;
 }
 
+/* developer / test hook: how many targets of the LAST large batch on this context the fast locator (certified leaf walk, or the
+   certified DAG walk) left to the exact kernel; *leafwalk = 1 when the locator data of "Certified leaf walk" is in place */
+extern "C" int gsl_sinterp_hip_bary_last_queue(gsl_sinterp_hip_ctx *ctx, unsigned *h_queued, int *h_leafwalk)
+{
+  REQUIRE(ctx, ctx != NULL && h_queued != NULL, ST_EFAULT);
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  *h_queued = 0;
+  if (h_leafwalk) *h_leafwalk = ctx->lw_rec != NULL;
+  if (!ctx->d_walk) return ST_SUCCESS;
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_OK(ctx, hipMemcpy(h_queued, ctx->lw_rec ? ctx->d_walk : (void *)((char *)ctx->d_walk + 0), sizeof(unsigned), hipMemcpyDeviceToHost));
+  return ST_SUCCESS;
+}
+
+/* a batch of >= 4096 targets through the certified leaf walk (records packed by tree_pack on this context) */
+static int bary_eval_leafwalk(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_records, const void *d_leaftab, const double *h_scale,
+                              const double *d_targets, size_t m, size_t ttda, double *d_values, int *d_leaf, unsigned long long *d_count)
+{
+  static const bool no_jump = getenv("GSL_SINTERP_NO_JUMP") && getenv("GSL_SINTERP_NO_JUMP")[0] == '1';
+  const bool have_table = !no_jump && ctx->jump_rec == d_records && ctx->jump_nodes == n_nodes && ctx->d_jumpt;
+  sinterp_sorted srt;
+  int st = sinterp_sort_reorder(ctx, d_targets, m, ttda, 2, 64, &srt, m, -1,
+                                have_table ? (const unsigned long long *)ctx->d_jumpt : (const unsigned long long *)NULL);
+  if (st) return st;
+  void *wb = NULL;
+  st = sinterp_walkbuf(ctx, 64 + m * sizeof(int), &wb);
+  if (st) return st;
+  unsigned *todo_count = (unsigned *)wb;
+  int *todo = (int *)((char *)wb + 64);
+  HIP_OK(ctx, hipMemsetAsync(todo_count, 0, 64, ctx->stream));
+  const bool via_map = srt.two_level;
+  double *vt = via_map ? srt.res1 : srt.vs;
+  int *lt = via_map ? (int *)srt.inv : (int *)NULL;
+  const int packed = (d_leaf != NULL ? 1 : 0) | (via_map ? 2 : 0);
+  LwGrid lg;
+  lg.lo0 = ctx->lw_lo[0]; lg.lo1 = ctx->lw_lo[1]; lg.w0 = ctx->lw_w[0]; lg.w1 = ctx->lw_w[1]; lg.G = ctx->lw_Gs;
+  const size_t cells = (size_t)ctx->lw_Gs * ctx->lw_Gs;
+  const int *seed = (const int *)((const char *)ctx->d_lw_a + 64);
+  const unsigned *off = (const unsigned *)(seed + 2 * cells);
+  hipLaunchKernelGGL(leafwalk_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
+                     (const LeafRec *)d_leaftab, seed, lg, off, (const double *)ctx->d_lw_lines, 8.0 * ctx->lw_K, ctx->lw_R, ctx->lw_c[0],
+                     ctx->lw_c[1], h_scale[0], h_scale[1], (const double *)srt.ys, m, (size_t)2, vt, lt, todo_count, todo, packed);
+  /* what the margin test (or the walk) left: the reference's arithmetic at every step of the DAG */
+  const int *d_jump = have_table ? (const int *)((const char *)ctx->d_jumpt + 64) : (const int *)NULL;
+  hipLaunchKernelGGL(bary_eval_kernel<true>, dim3(2048), dim3(256), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
+                     (const LeafRec *)d_leaftab, h_scale[0], h_scale[1], (const double *)srt.ys, m, (size_t)2, vt, lt, d_count, (const int *)todo,
+                     d_jump, have_table ? ctx->jump_G : 0, have_table ? (const unsigned long long *)ctx->d_jumpt : (const unsigned long long *)NULL,
+                     (const unsigned *)todo_count, packed);
+  LAUNCH_CHECK(ctx);
+  return (packed & 1) ? sinterp_unsort_packed(ctx, &srt, m, d_values, d_leaf) : sinterp_unsort(ctx, &srt, m, d_values, d_leaf);
+}
+
 extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_records,
                                          const void *d_leaftab, const double *h_scale, const double *d_targets,
                                          size_t m, size_t ttda, double *d_values, int *d_leaf,
@@ -1030,6 +1444,21 @@ extern "C" int gsl_sinterp_hip_bary_eval(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
   static const bool no_affine = getenv("GSL_SINTERP_NO_AFFINE_WALK") && getenv("GSL_SINTERP_NO_AFFINE_WALK")[0] == '1';
   static const bool no_side = getenv("GSL_SINTERP_NO_SIDE_STREAM") && getenv("GSL_SINTERP_NO_SIDE_STREAM")[0] == '1';
   const bool will_sort = m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1');
+  /* batches in cell order on records this context packed: the certified leaf walk (round 4) */
+  static const bool no_lw = getenv("GSL_SINTERP_NO_LEAFWALK") && getenv("GSL_SINTERP_NO_LEAFWALK")[0] == '1';
+  if (!no_lw && !no_fast && will_sort && m < 0x7fffffffULL && ctx->lw_rec == d_records && ctx->lw_nodes == n_nodes && ctx->d_lw_lines) {
+    int st = bary_eval_leafwalk(ctx, n_nodes, d_records, d_leaftab, h_scale, d_targets, m, ttda, d_values, d_leaf, d_count);
+    if (st) return st;
+    if (h_n_outside) {
+      unsigned long long cnt = 0;
+      HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_OK(ctx, hipMemcpy(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost));
+      HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+      *h_n_outside = (long long)cnt;
+      if (cnt) return sinterp_fail(ctx, ST_EDOM, "bary_eval: target(s) outside the caging simplex", hipSuccess, __FILE__, __LINE__);
+    }
+    return ST_SUCCESS;
+  }
   /* Large batches: per-batch affine walk records (a pass over the node records: ~n_nodes x 128 bytes) and the
      certified walk; what it could not certify is queued for the exact kernel.  The results do not depend on
      which kernel walked a target. */

@@ -57,6 +57,14 @@ struct gsl_sinterp_hip_ctx {
      [64 B box keys][G*G node indices]; valid for records == jump_rec with jump_nodes nodes */
   void *d_jumpt;
   size_t jumpt_bytes;
+  /* leaf-adjacency locator of the barycentric sweep (bary.hip, "Certified leaf walk"): seed grid + per-leaf line lists of the
+     final edges and of the historic (flipped-away) edges that cross the leaf, valid for records == lw_rec */
+  void *d_lw_a;             /* [64 B consts][seed Gs^2][off n_nodes + 1 + scan scratch] */
+  void *d_lw_lines;         /* 3 doubles per line */
+  size_t lw_a_bytes, lw_lines_bytes;
+  const void *lw_rec;
+  int lw_nodes, lw_Gs;
+  double lw_K, lw_R, lw_c[2], lw_lo[2], lw_w[2];
   const void *jump_rec;
   int jump_nodes, jump_G;
   int excl_depth;           /* nesting of sinterp_exclusive_begin/end */
@@ -188,6 +196,8 @@ int sinterp_unsort_packed(gsl_sinterp_hip_ctx *ctx, const sinterp_sorted *s, siz
 int sinterp_sort_centres(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, size_t xtda, int dim, int per_cell,
                          int **d_perm_out);
 int sinterp_sortbuf2(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
+/* exclusive scan of count[0..n) in place, total in count[n]; runsum: n/1024 + 2 entries of scratch (sort.hip) */
+void sinterp_scan_u32(gsl_sinterp_hip_ctx *ctx, unsigned *count, size_t n, unsigned *runsum);
 int sinterp_walkbuf(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);
 /* sort.hip: bounding box of n points as order-preserving keys, box[2c] = min, box[2c+1] = max (device, 48 bytes) */
 int sinterp_bbox_keys(gsl_sinterp_hip_ctx *ctx, const double *d_p, size_t n, size_t tda, int dim, unsigned long long *d_box);

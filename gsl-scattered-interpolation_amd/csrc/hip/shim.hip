@@ -79,6 +79,8 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_tf) (void)hipFree(ctx->d_tf);
   if (ctx->d_xq) (void)hipFree(ctx->d_xq);
   if (ctx->d_jumpt) (void)hipFree(ctx->d_jumpt);
+  if (ctx->d_lw_a) (void)hipFree(ctx->d_lw_a);
+  if (ctx->d_lw_lines) (void)hipFree(ctx->d_lw_lines);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -174,6 +174,8 @@ cell_scatter_kernel(const unsigned *__restrict__ cellid, const unsigned *__restr
 
 
 /* exclusive scan of count[0..ncell), total in count[ncell]; runsum needs ncell/1024 + 2 entries */
+static void launch_cell_scan(gsl_sinterp_hip_ctx *ctx, unsigned *count, size_t ncell, unsigned *runsum);
+void sinterp_scan_u32(gsl_sinterp_hip_ctx *ctx, unsigned *count, size_t n, unsigned *runsum) { launch_cell_scan(ctx, count, n, runsum); }
 static void launch_cell_scan(gsl_sinterp_hip_ctx *ctx, unsigned *count, size_t ncell, unsigned *runsum)
 {
   if (ncell <= 32768) {

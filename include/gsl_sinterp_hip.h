@@ -266,6 +266,10 @@ int gsl_sinterp_hip_gemm_minus(gsl_sinterp_hip_ctx *ctx, size_t m, size_t n, siz
                                size_t lda, const double *d_b, size_t ldb, int b_is_kn, double *d_c,
                                size_t ldc, int lower_only);
 
+/* developer / test hook: targets of the last large barycentric batch on this context that the certified leaf walk left to the
+   exact DAG kernel (meaningful when *h_leafwalk = 1: tree_pack built the locator data for the records in use) */
+int gsl_sinterp_hip_bary_last_queue(gsl_sinterp_hip_ctx *ctx, unsigned *h_queued, int *h_leafwalk);
+
 /* ---- gridded front-end: the targets of an n0 x n1 grid generated in HBM ---- */
 /* row (i*n1 + j) of d_y (packed M x 2) = (min0 + step0*i, min1 + step1*j): the loop of
    interpolation/scattered_interp_example.c:183-197, same operations, so the same bits */

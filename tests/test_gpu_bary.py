@@ -398,3 +398,38 @@ def test_two_level_reorder_matches_one_level_and_oracle(pkg, orc, monkeypatch, s
     ov, ol = o.eval_many(x, f, np.ascontiguousarray(y[idx]))
     ok = ol >= 0
     assert np.array_equal(l2[idx], ol) and np.array_equal(bits(v2[idx][ok]), bits(ov[ok]))
+
+
+def test_certified_leaf_walk_takes_the_bulk_and_queues_the_edges(pkg, orc):
+    """Round 4: batches of >= 4096 targets on records packed by tree_pack are located by a walk over the LEAVES' adjacency from a
+    grid seed and accepted only with a margin from every edge that can influence the reference's DAG descent (the leaf's own
+    edges + the flipped-away edges that cross it); everything else goes to the exact DAG kernel.  Leaf and value bit-exact;
+    the queue is tiny for targets in general position and takes every target placed on an edge or a vertex."""
+    import ctypes
+    n, m = 20000, 200_000
+    x = orc.synth_centres(n, 2)
+    f = orc.synth_response(x)
+    t, o = build_pair(pkg, orc, x)
+    d = t.device_alloc(0)
+    assert d.set_response(f) == 0
+    y = orc.synth_targets(0, m, 2) * 1.2 - 0.1                  # some outside the hull, in the cage leaves
+    st, v, l = d.eval_many(y)
+    q, lw = ctypes.c_uint(0), ctypes.c_int(0)
+    assert pkg.lib().gsl_sinterp_hip_bary_last_queue(pkg.lib().simplex_tree_device_ctx(d._h), ctypes.byref(q), ctypes.byref(lw)) == 0
+    assert lw.value == 1 and q.value < m // 200, (lw.value, q.value)
+    idx = np.arange(0, m, 41)
+    ov, ol = o.eval_many(x, f, np.ascontiguousarray(y[idx]))
+    assert st == 0 and np.array_equal(l[idx], ol) and np.array_equal(bits(v[idx]), bits(ov))
+    # targets ON data points, on edge midpoints of the final triangulation, and nudged off them by 1e-16 .. 1e-9
+    types, pidx, links = t.arrays()
+    sh = t.shuffle()
+    leaves = np.nonzero((types == 0) & (pidx.reshape(-1, 3) >= 0).all(axis=1))[0][:3000]
+    tri = sh[pidx.reshape(-1, 3)[leaves]]
+    mid = 0.5 * (x[tri[:, 0]] + x[tri[:, 1]])
+    hard = np.vstack([x[:3000], mid] + [mid + s * np.array([1.0, -0.7]) for s in (1e-16, 1e-14, 1e-12, 1e-10, 1e-9)])
+    hard = np.ascontiguousarray(np.vstack([hard, y[: 4096]]))
+    st2, v2, l2 = d.eval_many(hard)
+    assert pkg.lib().gsl_sinterp_hip_bary_last_queue(pkg.lib().simplex_tree_device_ctx(d._h), ctypes.byref(q), ctypes.byref(lw)) == 0
+    assert q.value >= 6000                                       # every on-vertex / on-edge target was left to the exact kernel
+    ov2, ol2 = o.eval_many(x, f, hard)
+    assert np.array_equal(l2, ol2) and np.array_equal(bits(v2), bits(ov2))

@@ -23,7 +23,7 @@ CASES = [
     ("GSL_SINTERP_NO_DATAFLOW_TRSV", LINALG), ("GSL_SINTERP_NO_DATAFLOW_TRSV", RBF_INIT),
     ("GSL_SINTERP_NO_SORT", RBF_SWEEP), ("GSL_SINTERP_NO_CULL", RBF_SWEEP), ("GSL_SINTERP_SERIAL_CELL_ORDER", RBF_SWEEP),
     ("GSL_SINTERP_SORT_LEVELS", BARY), ("GSL_SINTERP_SORT_LEVELS", RBF_SWEEP),      # "1": the one-level (atomic) target sort for every batch size
-    ("GSL_SINTERP_NO_SORT", BARY), ("GSL_SINTERP_NO_JUMP", BARY), ("GSL_SINTERP_NO_FASTDIV", BARY), ("GSL_SINTERP_NO_AFFINE_WALK", BARY), ("GSL_SINTERP_NO_SIDE_STREAM", BARY),
+    ("GSL_SINTERP_NO_SORT", BARY), ("GSL_SINTERP_NO_JUMP", BARY), ("GSL_SINTERP_NO_FASTDIV", BARY), ("GSL_SINTERP_NO_AFFINE_WALK", BARY), ("GSL_SINTERP_NO_SIDE_STREAM", BARY), ("GSL_SINTERP_NO_LEAFWALK", BARY),
 ]
 
 

@@ -18,7 +18,7 @@ expects gpurun_out/pmc/<CONFIG>_<COUNTER>/**/*counter_collection.csv.  Writes
 import collections, csv, glob, json, os, re, sys
 
 root = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 vals = collections.defaultdict(lambda: collections.defaultdict(list))     # (cfg, kernel) -> counter -> [values per dispatch]
 for d in sorted(glob.glob(os.path.join(root, "*_*"))):
     m = re.match(r"(C\d)_([A-Z0-9_]+)$", os.path.basename(d))
