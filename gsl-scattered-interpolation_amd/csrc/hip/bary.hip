@@ -26,6 +26,8 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 struct __attribute__((aligned(64))) NodeRec {
   double x0, x1;
@@ -944,40 +946,121 @@ __device__ __forceinline__ void atomic_max_nonneg(unsigned long long *dst, doubl
   atomicMax(dst, (unsigned long long)__double_as_longlong(v));
 }
 
-/* consts[0] = K bits, [1] = R bits, [2] = overflow flag, [3] = (unused) */
+/* Per-node error constants of the floating-point containment test, in Euclidean (raw-coordinate) terms:
+       | distance error of node N's test at p |  <=  kappa_N |p - x0_N|_1  <=  kappa_N |p - c|_1 + rho_N,
+   kappa_N = alpha_N h_N (alpha: the constant of the certified DAG walk, 64u x the forward error constant of solve_node;
+   h_N: the largest height), rho_N = kappa_N |x0_N - c|_1.  own[2 N], own[2 N + 1] = their bit patterns (non-negative
+   doubles order like their bits); +inf for nodes whose test cannot be bounded; 0 for singular nodes (rejected without a solve). */
 __global__ void __launch_bounds__(256)
 lw_bound_kernel(int n_nodes, const NodeRec *__restrict__ rec, double s0, double s1, double c0, double c1,
-                unsigned long long *__restrict__ consts)
+                unsigned long long *__restrict__ own, unsigned long long *__restrict__ acc, double tau_k, double tau_r)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_nodes) return;
+  const NodeRec r = rec[k];
   double kn = 0.0, rn = 0.0;
-  if (k < n_nodes) {
-    const NodeRec r = rec[k];
-    rn = fabs(r.x0 - c0) + fabs(r.x1 - c1);
-    if (!META_SINGULAR(r.meta)) {                       /* a singular node is rejected without a solve: no rounding involved */
-      const bool sw = META_SWAPPED(r.meta);
-      const double sa = sw ? s1 : s0, sb = sw ? s0 : s1;
-      const double m1a = -(r.l10 * sa) / r.u11, m1b = sb / r.u11;
-      const double m0a = (sa - r.u01 * m1a) / r.u00, m0b = -(r.u01 * m1b) / r.u00;
-      const double A1a = fabs(r.l10) * sa / fabs(r.u11), A1b = sb / fabs(r.u11);
-      const double A0a = (sa + fabs(r.u01) * A1a) / fabs(r.u00), A0b = fabs(r.u01) * A1b / fabs(r.u00);
-      const double alpha = fmax(A0a + A1a, A0b + A1b) * (0x1p-47 * (1.0 + 0x1p-10));    /* as walk_pack_kernel */
-      double g = 1.0;
-      const double v[6] = {r.l10, r.u01, r.u11, r.u00, sa, sb};
+  if (!META_SINGULAR(r.meta)) {
+    const bool sw = META_SWAPPED(r.meta);
+    const double sa = sw ? s1 : s0, sb = sw ? s0 : s1;
+    const double m1a = -(r.l10 * sa) / r.u11, m1b = sb / r.u11;
+    const double m0a = (sa - r.u01 * m1a) / r.u00, m0b = -(r.u01 * m1b) / r.u00;
+    const double A1a = fabs(r.l10) * sa / fabs(r.u11), A1b = sb / fabs(r.u11);
+    const double A0a = (sa + fabs(r.u01) * A1a) / fabs(r.u00), A0b = fabs(r.u01) * A1b / fabs(r.u00);
+    const double alpha = fmax(A0a + A1a, A0b + A1b) * (0x1p-47 * (1.0 + 0x1p-10));    /* as walk_pack_kernel */
+    double g = 1.0;
+    const double v[6] = {r.l10, r.u01, r.u11, r.u00, sa, sb};
 #pragma unroll
-      for (int i = 0; i < 6; i++) { const double a = fabs(v[i]); g *= fmax(1.0, a); if (i >= 2) g *= fmax(1.0, 1.0 / a); }
-      /* heights: 1 / |gradient| of the three coordinates (raw coordinates) */
-      const double g0 = sqrt(m0a * m0a + m0b * m0b), g1 = sqrt(m1a * m1a + m1b * m1b);
-      const double g2 = sqrt((m0a + m1a) * (m0a + m1a) + (m0b + m1b) * (m0b + m1b));
-      const double hmax = 1.0 / fmin(g0, fmin(g1, g2));
-      const bool ok = sa > 0.0 && sb > 0.0 && g <= 0x1p200 && alpha < 1e30;
-      kn = ok ? alpha * hmax * (1.0 + 0x1p-10) : INFINITY;
-      if (!(kn == kn)) kn = INFINITY;
+    for (int i = 0; i < 6; i++) { const double a = fabs(v[i]); g *= fmax(1.0, a); if (i >= 2) g *= fmax(1.0, 1.0 / a); }
+    const double g0 = sqrt(m0a * m0a + m0b * m0b), g1 = sqrt(m1a * m1a + m1b * m1b);
+    const double g2 = sqrt((m0a + m1a) * (m0a + m1a) + (m0b + m1b) * (m0b + m1b));
+    const double hmax = 1.0 / fmin(g0, fmin(g1, g2));
+    const bool ok = sa > 0.0 && sb > 0.0 && g <= 0x1p200 && alpha < 1e30;
+    /* the exact path's coordinates are within 12u q of the real-arithmetic ones (derivation above WalkRec); alpha carries 64u */
+    kn = ok ? alpha * (13.0 / 64.0) * hmax * (1.0 + 0x1p-10) : INFINITY;
+    if (!(kn >= 0.0)) kn = INFINITY;
+    rn = kn * (fabs(r.x0 - c0) + fabs(r.x1 - c1)) * (1.0 + 0x1p-10);
+    if (!(rn >= 0.0)) rn = INFINITY;
+  }
+  own[2 * (size_t)k] = (unsigned long long)__double_as_longlong(kn);
+  own[2 * (size_t)k + 1] = (unsigned long long)__double_as_longlong(rn);
+  /* a node's constants count for the targets that can reach its PARENT: lw_relax_kernel hands them down from there, except
+     for nodes with LARGE constants under a SMALL parent (cage-connected slivers: a far vertex and two nearby hull points) --
+     through flips the relaxation would carry those to almost every leaf; lw_region_kernel gives them to exactly the leaves
+     that overlap the parent's triangle */
+  (void)tau_k; (void)tau_r;
+  acc[2 * (size_t)k] = k == 0 ? own[0] : 0ULL;          /* the root is tested for every target; everything else arrives from a parent */
+  acc[2 * (size_t)k + 1] = k == 0 ? own[1] : 0ULL;
+}
+
+/* (P, child slot) pairs with large constants go by region unless the region turned out too large for the workgroup's
+   visited set (relax[4 P + slot] set by lw_region_kernel: the early, long cage-connected triangles) */
+__device__ __forceinline__ bool lw_by_region(const unsigned char *__restrict__ relax, int P, int slot, unsigned long long ok_,
+                                             unsigned long long or_, unsigned long long tau_k, unsigned long long tau_r)
+{
+  if (ok_ <= tau_k && or_ <= tau_r) return false;
+  return relax == NULL || relax[4 * (size_t)P + slot] == 0;
+}
+
+/* One relaxation sweep of  acc[N] = max(own[N], max over parents P of max(acc[P], own of P's children)):
+   after depth-of-the-DAG sweeps acc[L] bounds the constants of every node the reference walk can TEST on any way down
+   to L (the nodes on the way and their siblings).  changed: set when a value grew. */
+/* In topological order (Kahn): npar[c] counts the parents of c that have not handed their constants down yet; a node whose
+   count reaches zero in sweep `it` is final and hands its own down in sweep it + 1 (stamp[c] = it + 1).  Every node is
+   processed once, the number of sweeps is the depth of the DAG (72 at C5) and a sweep costs little more than reading the
+   stamps.  (The first version iterated "push to the children until nothing grows": 24 ms, the same nodes updated once per
+   ancestor level.) */
+__global__ void __launch_bounds__(256)
+lw_npar_kernel(int n_nodes, const NodeRec *__restrict__ rec, int *__restrict__ npar)
+{
+  const int P = blockIdx.x * blockDim.x + threadIdx.x;
+  if (P >= n_nodes) return;
+  const NodeRec r = rec[P];
+  if (META_TYPE(r.meta) == 0) return;
+  const int nc = META_NCHILD(r.meta);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int c = i == 0 ? r.child[0] : (i == 1 ? r.child[1] : r.child[2]);
+    if (i < nc && c > 0 && c < n_nodes) atomicAdd(&npar[c], 1);
+  }
+}
+__global__ void __launch_bounds__(256)
+lw_roots_kernel(int n_nodes, const int *__restrict__ npar, int *__restrict__ stamp)
+{
+  const int P = blockIdx.x * blockDim.x + threadIdx.x;
+  if (P < n_nodes) stamp[P] = npar[P] == 0 ? 0 : -1;
+}
+__global__ void __launch_bounds__(256)
+lw_relax_kernel(int n_nodes, const NodeRec *__restrict__ rec, const unsigned long long *__restrict__ own,
+                unsigned long long *__restrict__ acc, unsigned *__restrict__ changed, unsigned long long tau_k, unsigned long long tau_r,
+                const unsigned char *__restrict__ relax, int *__restrict__ stamp, int *__restrict__ npar, int it)
+{
+  const int P = blockIdx.x * blockDim.x + threadIdx.x;
+  if (P >= n_nodes) return;
+  if (stamp[P] != it) return;
+  const NodeRec r = rec[P];
+  if (META_TYPE(r.meta) == 0) return;
+  const int nc = META_NCHILD(r.meta);
+  unsigned long long v0 = acc[2 * (size_t)P], v1 = acc[2 * (size_t)P + 1];
+  int ch[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int c = i == 0 ? r.child[0] : (i == 1 ? r.child[1] : r.child[2]);
+    ch[i] = (i < nc && c > 0 && c < n_nodes) ? c : 0;
+    if (ch[i]) {
+      const unsigned long long o0 = own[2 * (size_t)ch[i]], o1 = own[2 * (size_t)ch[i] + 1];
+      if (!lw_by_region(relax, P, i, o0, o1, tau_k, tau_r)) { v0 = max(v0, o0); v1 = max(v1, o1); }
     }
   }
-  /* wave maximum, then one atomic per wave */
-  for (int off = 32; off > 0; off >>= 1) { kn = fmax(kn, __shfl_xor(kn, off)); rn = fmax(rn, __shfl_xor(rn, off)); }
-  if ((threadIdx.x & 63) == 0) { atomic_max_nonneg(&consts[0], kn); atomic_max_nonneg(&consts[1], rn); }
+  bool ready = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+    if (ch[i]) {
+      atomicMax(&acc[2 * (size_t)ch[i]], v0);
+      atomicMax(&acc[2 * (size_t)ch[i] + 1], v1);
+      /* no fence: the child reads acc in a later launch (a device-scope fence here writes the XCD's L2 back: 100 us a sweep) */
+      if (atomicSub(&npar[ch[i]], 1) == 1) { stamp[ch[i]] = it + 1; ready = true; }
+    }
+  if (ready) atomicExch(changed, 1u);
 }
 
 struct LwGrid { double lo0, lo1, w0, w1; int G; };
@@ -1008,20 +1091,36 @@ __device__ __forceinline__ void lw_line(double px, double py, double qx, double 
   out[0] = a; out[1] = b; out[2] = -(a * px + b * py);
 }
 
-/* does the segment P-Q come within LW_DELTA (barycentric) of the closed triangle of record r?  NaN / singular: yes */
-__device__ __forceinline__ bool lw_touches(const NodeRec &r, double px, double py, double qx, double qy, double s0, double s1)
+/* Can the segment e = (u, v) (vertex ids; P, Q their coordinates) meet the INTERIOR of the triangle of node y?  Conservative
+   (in doubt: yes), except where the answer is combinatorial: e is an edge of y (no); e starts at a vertex of y and leaves
+   through the outside of its angle there (no -- it touches y in that vertex only, and a segment that does not meet the
+   interior of a leaf is no closer to a target than the leaf's boundary is). */
+__device__ __forceinline__ bool lw_crosses(const NodeRec &r, const int *__restrict__ pid, int u, int v, double px, double py, double qx,
+                                           double qy, double s0, double s1)
 {
   if (META_SINGULAR(r.meta)) return true;
   double p0, p1, q0, q1;
   solve_node(r, px, py, s0, s1, p0, p1);
   solve_node(r, qx, qy, s0, s1, q0, q1);
   const double cp[3] = {p0, p1, 1.0 - p0 - p1}, cq[3] = {q0, q1, 1.0 - q0 - q1};
+  int ju = -1, jv = -1;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { if (pid[i] == u) ju = i; if (pid[i] == v) jv = i; }
+  if (ju >= 0 && jv >= 0) return false;                                /* an edge of y */
+  if (ju >= 0 || jv >= 0) {
+    /* from vertex j towards the other endpoint o: interior iff both other coordinates of o are positive */
+    const int j = ju >= 0 ? ju : jv;
+    const double *co = ju >= 0 ? cq : cp;
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) if (i != j) inside = inside && !(co[i] <= -LW_DELTA);      /* NaN: stays true */
+    return inside;
+  }
   double t0 = 0.0, t1 = 1.0;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     if (!(cp[i] == cp[i] && cq[i] == cq[i])) return true;
-    /* c(t) = cp + t (cq - cp) >= -delta */
-    const double a = cp[i] + LW_DELTA, d = cq[i] - cp[i];
+    const double a = cp[i] + LW_DELTA, d = cq[i] - cp[i];               /* c(t) = cp + t (cq - cp) >= -delta */
     if (d == 0.0) { if (a < 0.0) return false; continue; }
     const double tc = -a / d;
     if (d > 0.0) t0 = fmax(t0, tc); else t1 = fmin(t1, tc);
@@ -1029,21 +1128,30 @@ __device__ __forceinline__ bool lw_touches(const NodeRec &r, double px, double p
   return t0 <= t1 + 1e-12;
 }
 
-/* pass 0: cnt[leaf] += 1 for every (historic edge, leaf) incidence; pass 1: the lines themselves behind the leaf's own
-   three (off[leaf] + 3 + slot).  One thread per internal node A; its flipped-away edges = edges of A that no child keeps. */
+/* pass 0: cnt[leaf] += 1 for every (historic edge, leaf) incidence; pass 1: the lines themselves behind the leaf's header and
+   own three (off[leaf] + 4 + slot).  One thread per internal node A; its flipped-away edges = edges of A that no child keeps.
+   An edge whose sub-DAG is too large for the thread's stack / visited set (the long edges of the first insertions cross
+   hundreds of later triangles) is deferred to lw_push_big_kernel: nothing is committed for it here. */
+#define LW_LEAVES 24
 __global__ void __launch_bounds__(128)
 lw_push_kernel(int n_nodes, const int *__restrict__ type, const int *__restrict__ pidx, const int *__restrict__ links, int n_points,
                const double *__restrict__ points, Geom g, const NodeRec *__restrict__ rec, int pass, unsigned *__restrict__ cnt,
-               const unsigned *__restrict__ off, double *__restrict__ lines, unsigned long long *__restrict__ consts)
+               const unsigned *__restrict__ off, double *__restrict__ lines, unsigned long long *__restrict__ consts,
+               const unsigned long long *__restrict__ acc, const unsigned long long *__restrict__ lb, unsigned *__restrict__ big,
+               unsigned big_cap)
 {
   const int A = blockIdx.x * blockDim.x + threadIdx.x;
   if (A >= n_nodes) return;
   const int t = type[A];
   if (t == 0) {
-    if (pass == 1) {                                    /* the leaf's own edges open its list */
+    if (pass == 1) {                                    /* header {kappa, rho} + the leaf's own edges open its list */
       double vx[3], vy[3];
       for (int i = 0; i < 3; i++) lw_vertex(pidx[3 * A + i], points, n_points, g, vx[i], vy[i]);
-      for (int i = 0; i < 3; i++) lw_line(vx[(i + 1) % 3], vy[(i + 1) % 3], vx[(i + 2) % 3], vy[(i + 2) % 3], lines + 3 * ((size_t)off[A] + i));
+      double *hdr = lines + 3 * (size_t)off[A];
+      hdr[0] = __longlong_as_double((long long)max(acc[2 * (size_t)A], lb[2 * (size_t)A]));
+      hdr[1] = __longlong_as_double((long long)max(acc[2 * (size_t)A + 1], lb[2 * (size_t)A + 1]));
+      hdr[2] = 0.0;
+      for (int i = 0; i < 3; i++) lw_line(vx[(i + 1) % 3], vy[(i + 1) % 3], vx[(i + 2) % 3], vy[(i + 2) % 3], lines + 3 * ((size_t)off[A] + 1 + i));
     }
     return;
   }
@@ -1071,30 +1179,225 @@ lw_push_kernel(int n_nodes, const int *__restrict__ type, const int *__restrict_
     lw_vertex(u, points, n_points, g, px, py);
     lw_vertex(v, points, n_points, g, qx, qy);
     lw_line(px, py, qx, qy, ln);
-    int stack[LW_STACK], seen[LW_SEEN], sp = 0, ns = 0;
+    int stack[LW_STACK], seen[LW_SEEN], found[LW_LEAVES], sp = 0, ns = 0, nf = 0;
+    bool over = false;
     for (int i = 0; i < nch; i++) if (ch[i] > 0 && ch[i] < n_nodes) stack[sp++] = ch[i];
-    while (sp > 0) {
+    while (sp > 0 && !over) {
       const int y = stack[--sp];
       bool dup = false;
       for (int i = 0; i < ns; i++) dup = dup || seen[i] == y;
       if (dup) continue;
-      if (ns >= LW_SEEN) { atomicExch(&consts[2], 1ULL); return; }
+      if (ns >= LW_SEEN) { over = true; break; }
       seen[ns++] = y;
       const NodeRec r = rec[y];
-      if (!lw_touches(r, px, py, qx, qy, g.scale[0], g.scale[1])) continue;
+      if (!lw_crosses(r, pidx + 3 * (size_t)y, u, v, px, py, qx, qy, g.scale[0], g.scale[1])) continue;
       if (META_TYPE(r.meta) == 0) {
-        const unsigned slot = atomicAdd(&cnt[y], 1u);
-        if (pass == 1) { double *o = lines + 3 * ((size_t)off[y] + 3 + slot); o[0] = ln[0]; o[1] = ln[1]; o[2] = ln[2]; }
+        if (nf >= LW_LEAVES) { over = true; break; }
+        found[nf++] = y;
         continue;
       }
       const int nc = META_NCHILD(r.meta);
       for (int i = 0; i < nc; i++) {
         const int c = r.child[i];
         if (!(c > 0 && c < n_nodes)) continue;
-        if (sp >= LW_STACK) { atomicExch(&consts[2], 1ULL); return; }
+        if (sp >= LW_STACK) { over = true; break; }
         stack[sp++] = c;
       }
     }
+    if (over) {                                         /* the whole edge goes to the workgroup kernel */
+      const unsigned slot = atomicAdd(&big[0], 1u);
+      if (slot < big_cap) big[1 + slot] = (unsigned)(3 * A + e);
+      else atomicExch(&consts[2], 1ULL);
+      continue;
+    }
+    for (int i = 0; i < nf; i++) {
+      const int y = found[i];
+      const unsigned slot = atomicAdd(&cnt[y], 1u);
+      if (pass == 1) { double *o = lines + 3 * ((size_t)off[y] + 4 + slot); o[0] = ln[0]; o[1] = ln[1]; o[2] = ln[2]; }
+    }
+  }
+}
+
+/* the deferred (long) edges: one workgroup per edge, level-synchronous traversal with the frontier and the visited set in LDS */
+#define LWB_HASH 16384
+#define LWB_Q 6144
+__global__ void __launch_bounds__(256)
+lw_push_big_kernel(int n_nodes, const int *__restrict__ pidx, const int *__restrict__ links, const int *__restrict__ type, int n_points,
+                   const double *__restrict__ points, Geom g, const NodeRec *__restrict__ rec, int pass, unsigned *__restrict__ cnt,
+                   const unsigned *__restrict__ off, double *__restrict__ lines, unsigned long long *__restrict__ consts,
+                   const unsigned *__restrict__ big)
+{
+  __shared__ int s_hash[LWB_HASH];
+  __shared__ int s_q[2][LWB_Q];
+  __shared__ int s_n[2], s_fail;
+  const unsigned nbig = big[0];
+  for (unsigned w = blockIdx.x; w < nbig; w += gridDim.x) {
+    const int A = (int)(big[1 + w] / 3u), e = (int)(big[1 + w] % 3u);
+    const int u = pidx[3 * A + (e + 1) % 3], v = pidx[3 * A + (e + 2) % 3];
+    double px, py, qx, qy, ln[3];
+    lw_vertex(u, points, n_points, g, px, py);
+    lw_vertex(v, points, n_points, g, qx, qy);
+    lw_line(px, py, qx, qy, ln);
+    for (int i = threadIdx.x; i < LWB_HASH; i += blockDim.x) s_hash[i] = -1;
+    if (threadIdx.x == 0) {
+      const int nch = type[A] == 1 ? 3 : 2;
+      int n0 = 0;
+      for (int i = 0; i < nch; i++) { const int c = links[3 * A + i]; if (c > 0 && c < n_nodes) s_q[0][n0++] = c; }
+      s_n[0] = n0; s_n[1] = 0; s_fail = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) for (int i = 0; i < s_n[0]; i++) s_hash[((unsigned)s_q[0][i] * 2654435761u) % LWB_HASH] = s_q[0][i];   /* <= 3 distinct: collisions would only cost a revisit */
+    __syncthreads();
+    int cur = 0;
+    while (s_n[cur] > 0 && !s_fail) {
+      const int ncur = s_n[cur];
+      for (int i = threadIdx.x; i < ncur; i += blockDim.x) {
+        const int y = s_q[cur][i];
+        const NodeRec r = rec[y];
+        if (!lw_crosses(r, pidx + 3 * (size_t)y, u, v, px, py, qx, qy, g.scale[0], g.scale[1])) continue;
+        if (META_TYPE(r.meta) == 0) {
+          const unsigned slot = atomicAdd(&cnt[y], 1u);
+          if (pass == 1) { double *o = lines + 3 * ((size_t)off[y] + 4 + slot); o[0] = ln[0]; o[1] = ln[1]; o[2] = ln[2]; }
+          continue;
+        }
+        const int nc = META_NCHILD(r.meta);
+        for (int q = 0; q < nc; q++) {
+          const int c = q == 0 ? r.child[0] : (q == 1 ? r.child[1] : r.child[2]);
+          if (!(c > 0 && c < n_nodes)) continue;
+          /* visited set: open addressing; a node enters the next frontier exactly once */
+          unsigned h = ((unsigned)c * 2654435761u) % LWB_HASH;
+          bool fresh = false;
+          for (int probe = 0; probe < 64; probe++) {
+            const int old = atomicCAS(&s_hash[h], -1, c);
+            if (old == -1) { fresh = true; break; }
+            if (old == c) break;
+            h = (h + 1) % LWB_HASH;
+            if (probe == 63) s_fail = 1;
+          }
+          if (fresh) {
+            const int pos = atomicAdd(&s_n[cur ^ 1], 1);
+            if (pos < LWB_Q) s_q[cur ^ 1][pos] = c; else s_fail = 1;
+          }
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_n[cur] = 0;
+      cur ^= 1;
+      __syncthreads();
+    }
+    if (s_fail && threadIdx.x == 0) atomicExch(&consts[2], 1ULL);
+    __syncthreads();
+  }
+}
+
+/* (P, child) pairs whose child has large constants: pairs[0] = count, then P * 4 + child slot */
+__global__ void __launch_bounds__(256)
+lw_badpairs_kernel(int n_nodes, const NodeRec *__restrict__ rec, const unsigned long long *__restrict__ own, unsigned long long tau_k,
+                   unsigned long long tau_r, unsigned *__restrict__ pairs, unsigned cap, unsigned long long *__restrict__ consts)
+{
+  const int P = blockIdx.x * blockDim.x + threadIdx.x;
+  if (P >= n_nodes) return;
+  const NodeRec r = rec[P];
+  if (META_TYPE(r.meta) == 0) return;
+  const int nc = META_NCHILD(r.meta);
+  for (int i = 0; i < nc; i++) {
+    const int c = i == 0 ? r.child[0] : (i == 1 ? r.child[1] : r.child[2]);
+    if (!(c > 0 && c < n_nodes)) continue;
+    if (!lw_by_region((const unsigned char *)NULL, P, i, own[2 * (size_t)c], own[2 * (size_t)c + 1], tau_k, tau_r)) continue;
+    const unsigned slot = atomicAdd(&pairs[0], 1u);
+    if (slot < cap) pairs[1 + slot] = (unsigned)P * 4u + (unsigned)i;
+    else atomicExch(&consts[2], 1ULL);
+  }
+}
+
+/* may the closed triangles of P (vertices pv) and of node y (record r, vertex ids pid) share a point?  separating-edge test
+   in barycentric coordinates, conservative */
+__device__ __forceinline__ bool lw_tri_overlap(const NodeRec &rp, const double (&pvx)[3], const double (&pvy)[3], const NodeRec &ry,
+                                               const double (&yvx)[3], const double (&yvy)[3], double s0, double s1)
+{
+  if (META_SINGULAR(rp.meta) || META_SINGULAR(ry.meta)) return true;
+  for (int side = 0; side < 2; side++) {
+    const NodeRec &r = side ? ry : rp;
+    const double *vx = side ? pvx : yvx, *vy = side ? pvy : yvy;       /* the OTHER triangle's vertices in r's coordinates */
+    double c[3][3];
+    for (int k = 0; k < 3; k++) {
+      double a, b;
+      solve_node(r, vx[k], vy[k], s0, s1, a, b);
+      if (!(a == a && b == b)) return true;
+      c[k][0] = a; c[k][1] = b; c[k][2] = 1.0 - a - b;
+    }
+    for (int i = 0; i < 3; i++)
+      if (c[0][i] < -LW_DELTA && c[1][i] < -LW_DELTA && c[2][i] < -LW_DELTA) return false;     /* edge i of r separates */
+  }
+  return true;
+}
+
+/* one workgroup per (P, bad child): every leaf whose triangle may overlap P's -- the region in which the reference can test
+   the child -- takes the child's constants (atomicMax into lb[2 leaf], lb[2 leaf + 1]) */
+__global__ void __launch_bounds__(256)
+lw_region_kernel(int n_nodes, const int *__restrict__ pidx, int n_points, const double *__restrict__ points, Geom g,
+                 const NodeRec *__restrict__ rec, const unsigned long long *__restrict__ own, const unsigned *__restrict__ pairs,
+                 unsigned long long *__restrict__ lb, unsigned char *__restrict__ relax)
+{
+  __shared__ int s_hash[LWB_HASH];
+  __shared__ int s_q[2][LWB_Q];
+  __shared__ int s_n[2], s_fail;
+  const unsigned npairs = pairs[0];
+  for (unsigned w = blockIdx.x; w < npairs; w += gridDim.x) {
+    const int P = (int)(pairs[1 + w] / 4u), ci = (int)(pairs[1 + w] % 4u);
+    const NodeRec rp = rec[P];
+    const int bad = ci == 0 ? rp.child[0] : (ci == 1 ? rp.child[1] : rp.child[2]);
+    const unsigned long long bk = own[2 * (size_t)bad], br = own[2 * (size_t)bad + 1];
+    double pvx[3], pvy[3];
+    for (int i = 0; i < 3; i++) lw_vertex(pidx[3 * P + i], points, n_points, g, pvx[i], pvy[i]);
+    for (int i = threadIdx.x; i < LWB_HASH; i += blockDim.x) s_hash[i] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int nc = META_NCHILD(rp.meta);
+      int n0 = 0;
+      for (int i = 0; i < nc; i++) {
+        const int c = i == 0 ? rp.child[0] : (i == 1 ? rp.child[1] : rp.child[2]);
+        if (c > 0 && c < n_nodes) { s_q[0][n0++] = c; s_hash[((unsigned)c * 2654435761u) % LWB_HASH] = c; }
+      }
+      s_n[0] = n0; s_n[1] = 0; s_fail = 0;
+    }
+    __syncthreads();
+    int cur = 0;
+    while (s_n[cur] > 0 && !s_fail) {
+      const int ncur = s_n[cur];
+      for (int i = threadIdx.x; i < ncur; i += blockDim.x) {
+        const int y = s_q[cur][i];
+        const NodeRec r = rec[y];
+        double yvx[3], yvy[3];
+        for (int k = 0; k < 3; k++) lw_vertex(pidx[3 * (size_t)y + k], points, n_points, g, yvx[k], yvy[k]);
+        if (!lw_tri_overlap(rp, pvx, pvy, r, yvx, yvy, g.scale[0], g.scale[1])) continue;
+        if (META_TYPE(r.meta) == 0) { atomicMax(&lb[2 * (size_t)y], bk); atomicMax(&lb[2 * (size_t)y + 1], br); continue; }
+        const int nc = META_NCHILD(r.meta);
+        for (int q = 0; q < nc; q++) {
+          const int c = q == 0 ? r.child[0] : (q == 1 ? r.child[1] : r.child[2]);
+          if (!(c > 0 && c < n_nodes)) continue;
+          unsigned h = ((unsigned)c * 2654435761u) % LWB_HASH;
+          bool fresh = false;
+          for (int probe = 0; probe < 64; probe++) {
+            const int old = atomicCAS(&s_hash[h], -1, c);
+            if (old == -1) { fresh = true; break; }
+            if (old == c) break;
+            h = (h + 1) % LWB_HASH;
+            if (probe == 63) s_fail = 1;
+          }
+          if (fresh) {
+            const int pos = atomicAdd(&s_n[cur ^ 1], 1);
+            if (pos < LWB_Q) s_q[cur ^ 1][pos] = c; else s_fail = 1;
+          }
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_n[cur] = 0;
+      cur ^= 1;
+      __syncthreads();
+    }
+    if (s_fail && threadIdx.x == 0) relax[pairs[1 + w]] = 1;       /* too large a region: this pair is relaxed from P instead */
+    __syncthreads();
   }
 }
 
@@ -1122,16 +1425,13 @@ __device__ __forceinline__ void leaf_finish(const NodeRec &cur, const LeafRec *_
   store_result(values, leaf_out, k, interp, t, packed);
 }
 
-/* one target per lane (cell order); todo_count / todo: the queue of the exact kernel */
-__global__ void __launch_bounds__(256)
-leafwalk_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, const int *__restrict__ seed, LwGrid g,
-                const unsigned *__restrict__ off, const double *__restrict__ lines, double K2, double R, double c0c, double c1c,
-                double s0, double s1, const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
-                int *__restrict__ leaf_out, unsigned *__restrict__ todo_count, int *__restrict__ todo, int packed)
+/* one target per lane and slice (cell order).  Returns true when the target was finished here. */
+__device__ __forceinline__ bool leafwalk_target(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab,
+                                                const int *__restrict__ seed, const LwGrid &g, const unsigned *__restrict__ off,
+                                                const double *__restrict__ lines, double F, double c0c, double c1c, double s0, double s1,
+                                                double y0, double y1, size_t k, double *__restrict__ values, int *__restrict__ leaf_out,
+                                                int packed)
 {
-  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= m) return;
-  const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
   int found = -1;
   double c0 = 0.0, c1 = 0.0;
   NodeRec cur;
@@ -1158,19 +1458,66 @@ leafwalk_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__r
       t = next;
     }
   }
+  /* The margin test: E(p) = F (kappa_L |p - c|_1 + rho_L); kappa_L, rho_L bound every test the reference can make on its way
+     to this leaf.  Eight lines per trip, their loads in flight together with the header's: one line per trip is a chain of
+     ~13 dependent L2 round trips (0.62 ms -> 0.56 ms at C5; the walk alone is 0.38 ms).  Past the end: the last line again.
+     (Taking the wave's leaves one at a time with the list read through the scalar cache -- uniform addresses -- was slower at
+     every trip count tried, 0.65-0.68 ms.) */
   bool safe = found >= 0;
   if (safe) {
-    const double E = K2 * (fabs(y0 - c0c) + fabs(y1 - c1c) + R);
     const unsigned b = off[found], e = off[found + 1];
-    safe = E == E && E < INFINITY;
-    for (unsigned i = b; i < e && safe; i++) {
-      const double d = lines[3 * (size_t)i] * y0 + lines[3 * (size_t)i + 1] * y1 + lines[3 * (size_t)i + 2];
-      safe = fabs(d) > E;                                 /* NaN -> false */
+    safe = e > b + 1;
+    const size_t last = e > b ? e - 1 : b;
+    double d[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const size_t ii = min((size_t)b + 1 + j, last);
+      d[j] = lines[3 * ii] * y0 + lines[3 * ii + 1] * y1 + lines[3 * ii + 2];
+    }
+    const double E = F * (lines[3 * (size_t)b] * (fabs(y0 - c0c) + fabs(y1 - c1c)) + lines[3 * (size_t)b + 1]);
+    safe = safe && E == E && E < INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; j++) safe = safe && fabs(d[j]) > E;                /* NaN -> false */
+    for (unsigned i = b + 9; i < e && safe; i += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const size_t ii = min((size_t)i + j, last);
+        d[j] = lines[3 * ii] * y0 + lines[3 * ii + 1] * y1 + lines[3 * ii + 2];
+      }
+      safe = fabs(d[0]) > E && fabs(d[1]) > E && fabs(d[2]) > E && fabs(d[3]) > E;
     }
   }
-  if (safe) { leaf_finish(cur, tab, found, c0, c1, k, values, leaf_out, packed); return; }
-  const unsigned slot = atomicAdd(todo_count, 1u);
-  todo[slot] = (int)k;
+  if (safe) leaf_finish(cur, tab, found, c0, c1, k, values, leaf_out, packed);
+  return safe;
+}
+
+/* LW_SLICES x 256 consecutive targets per workgroup; what the margin test leaves is gathered in LDS and appended to the
+   exact kernel's queue (todo_count / todo) with ONE atomic per workgroup: at ~1 % queued, one atomic per target on the
+   single counter cost more than the walk itself (0.92 ms against 0.4 ms at C5). */
+#define LW_SLICES 8
+__global__ void __launch_bounds__(256)
+leafwalk_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, const int *__restrict__ seed, LwGrid g,
+                const unsigned *__restrict__ off, const double *__restrict__ lines, double F, double c0c, double c1c,
+                double s0, double s1, const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
+                int *__restrict__ leaf_out, unsigned *__restrict__ todo_count, int *__restrict__ todo, int packed)
+{
+  __shared__ int s_q[LW_SLICES * 256];
+  __shared__ unsigned s_nq, s_base;
+  if (threadIdx.x == 0) s_nq = 0;
+  __syncthreads();
+  for (int sl = 0; sl < LW_SLICES; sl++) {
+    const size_t k = ((size_t)blockIdx.x * LW_SLICES + sl) * 256 + threadIdx.x;
+    if (k >= m) break;
+    const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
+    if (!leafwalk_target(n_nodes, rec, tab, seed, g, off, lines, F, c0c, c1c, s0, s1, y0, y1, k, values, leaf_out, packed))
+      s_q[atomicAdd(&s_nq, 1u)] = (int)k;
+  }
+  __syncthreads();
+  const unsigned nq = s_nq;
+  if (nq == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(todo_count, nq);
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < nq; i += 256) todo[s_base + i] = s_q[i];
 }
 
 static int lw_build(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type, const int *d_pidx, const int *d_links, int n_points,
@@ -1186,14 +1533,27 @@ static int lw_build(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type, co
     HIP_OK(ctx, hipMalloc(&ctx->d_lw_a, a_bytes));
     ctx->lw_a_bytes = a_bytes;
   }
-  unsigned long long *consts = (unsigned long long *)ctx->d_lw_a;
+  unsigned long long *consts = (unsigned long long *)ctx->d_lw_a;      /* [2] overflow flag, [3] low word: relaxation "changed" */
   int *seed = (int *)((char *)ctx->d_lw_a + 64), *seed_raw = seed + cells;
   unsigned *off = (unsigned *)(seed_raw + cells), *runsum = off + n_nodes + 1;
-  /* bounding box of the data (the jump table's keys when it was built, else computed here) */
+  /* scratch of the build (the context's second sort buffer): per-node constants own / acc (4 x 8 B) + fill counters */
+  void *sb = NULL;
+  int st = sinterp_sortbuf2(ctx, (size_t)n_nodes * 6 * sizeof(unsigned long long) + ((size_t)n_nodes + 1) * sizeof(unsigned) + 12 * (size_t)n_nodes + 64, &sb);
+  if (st) return st;
+  unsigned long long *own = (unsigned long long *)sb, *acc = own + 2 * (size_t)n_nodes, *lb = acc + 2 * (size_t)n_nodes;
+  unsigned *fillcnt = (unsigned *)(lb + 2 * (size_t)n_nodes);
+  unsigned char *relax = (unsigned char *)(fillcnt + n_nodes + 1);
+  int *stamp = (int *)(relax + 4 * (size_t)n_nodes), *npar = stamp + n_nodes;     /* see lw_relax_kernel */
+  const unsigned big_cap = (unsigned)n_nodes;            /* deferred (long) edges: [0] = count */
+  void *bb = NULL;
+  st = sinterp_walkbuf(ctx, ((size_t)big_cap + 1) * sizeof(unsigned), &bb);
+  if (st) return st;
+  unsigned *big = (unsigned *)bb;
+  /* bounding box of the data */
   unsigned long long hbox[4];
   {
     unsigned long long *d_box = (unsigned long long *)((char *)ctx->d_lw_a + 32);     /* bytes 32..63 of the header */
-    int st = sinterp_bbox_keys(ctx, d_points, (size_t)n_points, 2, 2, d_box);
+    st = sinterp_bbox_keys(ctx, d_points, (size_t)n_points, 2, 2, d_box);
     if (st) return st;
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
     HIP_OK(ctx, hipMemcpy(hbox, d_box, sizeof hbox, hipMemcpyDeviceToHost));
@@ -1206,15 +1566,51 @@ static int lw_build(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type, co
   const double c0 = 0.5 * (lo0 + hi0), c1 = 0.5 * (lo1 + hi1);
   HIP_OK(ctx, hipMemsetAsync(consts, 0, 32, ctx->stream));
   const unsigned nb = (unsigned)((n_nodes + 255) / 256);
-  hipLaunchKernelGGL(lw_bound_kernel, dim3(nb), dim3(256), 0, ctx->stream, n_nodes, d_records, g.scale[0], g.scale[1], c0, c1, consts);
+  /* constants above tau (a margin of ~1e-7 of the data's extent) stay out of the relaxation and are pushed by region */
+  const double ext = (hi0 - lo0) + (hi1 - lo1), tau_r = 5e-8 * ext, tau_k = 5e-8;
+  unsigned long long tk_bits, tr_bits;
+  memcpy(&tk_bits, &tau_k, 8); memcpy(&tr_bits, &tau_r, 8);
+  hipLaunchKernelGGL(lw_bound_kernel, dim3(nb), dim3(256), 0, ctx->stream, n_nodes, d_records, g.scale[0], g.scale[1], c0, c1, own, acc, tau_k, tau_r);
+  HIP_OK(ctx, hipMemsetAsync(lb, 0, (size_t)n_nodes * 2 * sizeof(unsigned long long), ctx->stream));
+  HIP_OK(ctx, hipMemsetAsync(relax, 0, 4 * (size_t)n_nodes, ctx->stream));
+  HIP_OK(ctx, hipMemsetAsync(npar, 0, sizeof(int) * (size_t)n_nodes, ctx->stream));
+  hipLaunchKernelGGL(lw_npar_kernel, dim3(nb), dim3(256), 0, ctx->stream, n_nodes, d_records, npar);
+  hipLaunchKernelGGL(lw_roots_kernel, dim3(nb), dim3(256), 0, ctx->stream, n_nodes, (const int *)npar, stamp);
+  /* the large constants, by region */
+  HIP_OK(ctx, hipMemsetAsync(big, 0, sizeof(unsigned), ctx->stream));
+  hipLaunchKernelGGL(lw_badpairs_kernel, dim3(nb), dim3(256), 0, ctx->stream, n_nodes, d_records, (const unsigned long long *)own, tk_bits, tr_bits,
+                     big, big_cap, consts);
+  hipLaunchKernelGGL(lw_region_kernel, dim3(512), dim3(256), 0, ctx->stream, n_nodes, d_pidx, n_points, d_points, g, d_records,
+                     (const unsigned long long *)own, (const unsigned *)big, lb, relax);
+  if (getenv("GSL_SINTERP_LW_DEBUG") && getenv("GSL_SINTERP_LW_DEBUG")[0] == '1') {
+    unsigned np_ = 0;
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipMemcpy(&np_, big, sizeof np_, hipMemcpyDeviceToHost);
+    fprintf(stderr, "leaf walk: %u (parent, child) pairs with large constants pushed by region\n", np_);
+  }
+  /* the constants handed down the DAG, one level of its depth per sweep (lw_relax_kernel) */
+  unsigned *changed = (unsigned *)&consts[3];
+  for (int it = 0; it < 4096; it += 8) {
+    HIP_OK(ctx, hipMemsetAsync(changed, 0, sizeof(unsigned), ctx->stream));
+    for (int q = 0; q < 8; q++)
+      hipLaunchKernelGGL(lw_relax_kernel, dim3(nb), dim3(256), 0, ctx->stream, n_nodes, d_records, (const unsigned long long *)own, acc, changed, tk_bits, tr_bits, (const unsigned char *)relax, stamp, npar, it + q);
+    unsigned hch = 0;
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_OK(ctx, hipMemcpy(&hch, changed, sizeof hch, hipMemcpyDeviceToHost));
+    if (!hch) break;
+    if (it + 8 >= 4096) return ST_SUCCESS;              /* did not settle: no fast path */
+  }
   hipLaunchKernelGGL(mesh_seed_init_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, seed_raw, cells);
   hipLaunchKernelGGL(lw_seed_kernel, dim3(nb), dim3(256), 0, ctx->stream, n_nodes, d_type, d_pidx, n_points, d_points, lg, seed_raw);
   hipLaunchKernelGGL(mesh_seed_fill_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, (const int *)seed_raw, seed, Gs);
-  /* pass 0: list lengths (3 own edges per leaf + the historic edges that reach it), scan, pass 1: the lines */
-  hipLaunchKernelGGL(lw_cnt_init_kernel, dim3((unsigned)((n_nodes + 256) / 256)), dim3(256), 0, ctx->stream, n_nodes, d_type, off, 3u);
+  /* pass 0: list lengths (header + 3 own edges per leaf + the historic edges that reach it), scan, pass 1: the lines */
+  hipLaunchKernelGGL(lw_cnt_init_kernel, dim3((unsigned)((n_nodes + 256) / 256)), dim3(256), 0, ctx->stream, n_nodes, d_type, off, 4u);
   const unsigned pb = (unsigned)((n_nodes + 127) / 128);
+  HIP_OK(ctx, hipMemsetAsync(big, 0, sizeof(unsigned), ctx->stream));
   hipLaunchKernelGGL(lw_push_kernel, dim3(pb), dim3(128), 0, ctx->stream, n_nodes, d_type, d_pidx, d_links, n_points, d_points, g, d_records,
-                     0, off, (const unsigned *)NULL, (double *)NULL, consts);
+                     0, off, (const unsigned *)NULL, (double *)NULL, consts, (const unsigned long long *)acc, (const unsigned long long *)lb, big, big_cap);
+  hipLaunchKernelGGL(lw_push_big_kernel, dim3(512), dim3(256), 0, ctx->stream, n_nodes, d_pidx, d_links, d_type, n_points, d_points, g, d_records,
+                     0, off, (const unsigned *)NULL, (double *)NULL, consts, (const unsigned *)big);
   sinterp_scan_u32(ctx, off, (size_t)n_nodes, runsum);
   LAUNCH_CHECK(ctx);
   unsigned long long hc[4] = {0, 0, 0, 0};
@@ -1222,29 +1618,31 @@ static int lw_build(gsl_sinterp_hip_ctx *ctx, int n_nodes, const int *d_type, co
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
   HIP_OK(ctx, hipMemcpy(hc, consts, 32, hipMemcpyDeviceToHost));
   HIP_OK(ctx, hipMemcpy(&total, off + n_nodes, sizeof total, hipMemcpyDeviceToHost));
-  double K, R;
-  memcpy(&K, &hc[0], sizeof K); memcpy(&R, &hc[1], sizeof R);
-  if (hc[2] != 0 || !(K >= 0.0 && K < 1e-3) || !(R >= 0.0 && R < INFINITY) || total == 0) return ST_SUCCESS;   /* not certifiable: DAG walk */
+  static const bool dbg = getenv("GSL_SINTERP_LW_DEBUG") && getenv("GSL_SINTERP_LW_DEBUG")[0] == '1';
+  if (dbg) {
+    unsigned nbig = 0;
+    (void)hipMemcpy(&nbig, big, sizeof nbig, hipMemcpyDeviceToHost);
+    fprintf(stderr, "leaf walk: nodes %d, seed grid %d, overflow %llu, list entries %u, long edges %u\n", n_nodes, Gs, hc[2], total, nbig);
+  }
+  if (hc[2] != 0 || total == 0) return ST_SUCCESS;      /* a sub-DAG too large for the push kernel's stack: certified DAG walk */
   const size_t l_bytes = (size_t)total * 3 * sizeof(double);
   if (l_bytes > ctx->lw_lines_bytes) {
     if (ctx->d_lw_lines) { HIP_OK(ctx, hipFree(ctx->d_lw_lines)); ctx->d_lw_lines = NULL; ctx->lw_lines_bytes = 0; }
     HIP_OK(ctx, hipMalloc(&ctx->d_lw_lines, l_bytes));
     ctx->lw_lines_bytes = l_bytes;
   }
-  /* the fill pass re-counts into a scratch copy of the counters (the sort buffer) */
-  void *sb = NULL;
-  int st = sinterp_sortbuf2(ctx, ((size_t)n_nodes + 1) * sizeof(unsigned), &sb);
-  if (st) return st;
-  unsigned *fillcnt = (unsigned *)sb;
   hipLaunchKernelGGL(lw_cnt_zero_kernel, dim3((unsigned)((n_nodes + 256) / 256)), dim3(256), 0, ctx->stream, n_nodes + 1, fillcnt);
+  HIP_OK(ctx, hipMemsetAsync(big, 0, sizeof(unsigned), ctx->stream));
   hipLaunchKernelGGL(lw_push_kernel, dim3(pb), dim3(128), 0, ctx->stream, n_nodes, d_type, d_pidx, d_links, n_points, d_points, g, d_records,
-                     1, fillcnt, (const unsigned *)off, (double *)ctx->d_lw_lines, consts);
+                     1, fillcnt, (const unsigned *)off, (double *)ctx->d_lw_lines, consts, (const unsigned long long *)acc, (const unsigned long long *)lb, big, big_cap);
+  hipLaunchKernelGGL(lw_push_big_kernel, dim3(512), dim3(256), 0, ctx->stream, n_nodes, d_pidx, d_links, d_type, n_points, d_points, g, d_records,
+                     1, fillcnt, (const unsigned *)off, (double *)ctx->d_lw_lines, consts, (const unsigned *)big);
   LAUNCH_CHECK(ctx);
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
   HIP_OK(ctx, hipMemcpy(hc, consts, 32, hipMemcpyDeviceToHost));
   if (hc[2] != 0) return ST_SUCCESS;
   ctx->lw_rec = d_records; ctx->lw_nodes = n_nodes; ctx->lw_Gs = Gs;
-  ctx->lw_K = K; ctx->lw_R = R; ctx->lw_c[0] = c0; ctx->lw_c[1] = c1;
+  ctx->lw_c[0] = c0; ctx->lw_c[1] = c1;
   ctx->lw_lo[0] = lo0; ctx->lw_lo[1] = lo1; ctx->lw_w[0] = lg.w0; ctx->lw_w[1] = lg.w1;
   return ST_SUCCESS;
 }
@@ -1260,6 +1658,7 @@ static int bary_eval_part(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_r
   static const bool no_fast = getenv("GSL_SINTERP_NO_FASTDIV") && getenv("GSL_SINTERP_NO_FASTDIV")[0] == '1';
   const bool will_sort = m >= 4096 && !(getenv("GSL_SINTERP_NO_SORT") && getenv("GSL_SINTERP_NO_SORT")[0] == '1');
   const bool use_walk = wrec != NULL;
+  ctx->lw_last = 0;
   const unsigned n_slices = (unsigned)((m + WALK_SLICE - 1) / WALK_SLICE);
   unsigned *todo_count = NULL;
   int *todo = NULL;
@@ -1374,13 +1773,13 @@ static int bary_eval_part(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void *d_r
 }
 
 /* developer / test hook: how many targets of the LAST large batch on this context the fast locator (certified leaf walk, or the
-   certified DAG walk) left to the exact kernel; *leafwalk = 1 when the locator data of "Certified leaf walk" is in place */
+   certified DAG walk) left to the exact kernel; *leafwalk = 1 when that batch went through the certified leaf walk */
 extern "C" int gsl_sinterp_hip_bary_last_queue(gsl_sinterp_hip_ctx *ctx, unsigned *h_queued, int *h_leafwalk)
 {
   REQUIRE(ctx, ctx != NULL && h_queued != NULL, ST_EFAULT);
   HIP_OK(ctx, hipSetDevice(ctx->device));
   *h_queued = 0;
-  if (h_leafwalk) *h_leafwalk = ctx->lw_rec != NULL;
+  if (h_leafwalk) *h_leafwalk = ctx->lw_last;
   if (!ctx->d_walk) return ST_SUCCESS;
   HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
   HIP_OK(ctx, hipMemcpy(h_queued, ctx->lw_rec ? ctx->d_walk : (void *)((char *)ctx->d_walk + 0), sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -1407,13 +1806,15 @@ static int bary_eval_leafwalk(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void 
   double *vt = via_map ? srt.res1 : srt.vs;
   int *lt = via_map ? (int *)srt.inv : (int *)NULL;
   const int packed = (d_leaf != NULL ? 1 : 0) | (via_map ? 2 : 0);
+  static const double lwF = getenv("GSL_SINTERP_LW_F") ? atof(getenv("GSL_SINTERP_LW_F")) : 4.0;   /* developer */
+  ctx->lw_last = 1;
   LwGrid lg;
   lg.lo0 = ctx->lw_lo[0]; lg.lo1 = ctx->lw_lo[1]; lg.w0 = ctx->lw_w[0]; lg.w1 = ctx->lw_w[1]; lg.G = ctx->lw_Gs;
   const size_t cells = (size_t)ctx->lw_Gs * ctx->lw_Gs;
   const int *seed = (const int *)((const char *)ctx->d_lw_a + 64);
   const unsigned *off = (const unsigned *)(seed + 2 * cells);
-  hipLaunchKernelGGL(leafwalk_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
-                     (const LeafRec *)d_leaftab, seed, lg, off, (const double *)ctx->d_lw_lines, 8.0 * ctx->lw_K, ctx->lw_R, ctx->lw_c[0],
+  hipLaunchKernelGGL(leafwalk_kernel, dim3((unsigned)((m + LW_SLICES * 256 - 1) / (LW_SLICES * 256))), dim3(256), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
+                     (const LeafRec *)d_leaftab, seed, lg, off, (const double *)ctx->d_lw_lines, lwF, ctx->lw_c[0],
                      ctx->lw_c[1], h_scale[0], h_scale[1], (const double *)srt.ys, m, (size_t)2, vt, lt, todo_count, todo, packed);
   /* what the margin test (or the walk) left: the reference's arithmetic at every step of the DAG */
   const int *d_jump = have_table ? (const int *)((const char *)ctx->d_jumpt + 64) : (const int *)NULL;

@@ -63,8 +63,8 @@ struct gsl_sinterp_hip_ctx {
   void *d_lw_lines;         /* 3 doubles per line */
   size_t lw_a_bytes, lw_lines_bytes;
   const void *lw_rec;
-  int lw_nodes, lw_Gs;
-  double lw_K, lw_R, lw_c[2], lw_lo[2], lw_w[2];
+  int lw_nodes, lw_Gs, lw_last;   /* lw_last: the last large batch went through the leaf walk */
+  double lw_c[2], lw_lo[2], lw_w[2];
   const void *jump_rec;
   int jump_nodes, jump_G;
   int excl_depth;           /* nesting of sinterp_exclusive_begin/end */
