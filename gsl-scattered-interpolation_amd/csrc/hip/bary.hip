@@ -840,7 +840,7 @@ extern "C" int gsl_sinterp_hip_tree_pack(gsl_sinterp_hip_ctx *ctx, int n_nodes, 
     /* cells per node: what stops the descent of a cell is a HISTORIC edge crossing it (flips leave them all over the final
        triangles), so the share of targets that start at their leaf grows with the resolution -- measured at C5 (450 k nodes,
        per step): G = 2048: 1.94 ms, 4096 (40 cells per node, the round-2 rule): 1.67, 8192: 1.57, 16384: 1.61 (the table no
-       longer stays in the Infinity Cache).  160 cells per node, at most 8192^2 (256 MB, built once per tree in ~50 ms).
+       longer stays in the Infinity Cache).  90 cells per node, at most 8192^2 (256 MB; built coarse-to-fine once per tree, 14.5 ms at C5).
        Developer knobs: GSL_SINTERP_JUMP_GMAX / GSL_SINTERP_JUMP_FACTOR */
     const int gcap = getenv("GSL_SINTERP_JUMP_GMAX") ? atoi(getenv("GSL_SINTERP_JUMP_GMAX")) : 8192;
     const double gfac = getenv("GSL_SINTERP_JUMP_FACTOR") ? atof(getenv("GSL_SINTERP_JUMP_FACTOR")) : JUMP_CELLS_PER_NODE;
