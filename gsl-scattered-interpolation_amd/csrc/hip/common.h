@@ -53,6 +53,7 @@ struct gsl_sinterp_hip_ctx {
   unsigned *d_tf;
   size_t tf_count;
   unsigned long long *d_xq; /* hand-off buffer of the sweeps: per entry {epoch|lo32}, {epoch|hi32} */
+  void *d_lu_coop;          /* cooperative LU panel: [generation, abort] + exchange slots (lu.hip) */
   /* jump table of the barycentric walk built by tree_pack over the data's bounding box (bary.hip):
      [64 B box keys][G*G node indices]; valid for records == jump_rec with jump_nodes nodes */
   void *d_jumpt;

@@ -21,6 +21,17 @@
 #include <math.h>
 #include <stdlib.h>
 
+#ifdef SINTERP_DIAG_PROF
+__device__ unsigned long long g_lu_ts[128];
+#define LU_TSTAMP(i) do { if (threadIdx.x == 0 && j0 == 0) g_lu_ts[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int gsl_sinterp_hip_debug_lu_ts(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lu_ts), sizeof(unsigned long long) * 128); }
+__device__ unsigned long long g_lc_ts[6 * 64 + 2];
+#define LC_TSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && j0 == 0) g_lc_ts[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int gsl_sinterp_hip_debug_lc_ts(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lc_ts), sizeof(unsigned long long) * (6 * 64 + 2)); }
+#else
+#define LU_TSTAMP(i) do { } while (0)
+#define LC_TSTAMP(i) do { } while (0)
+#endif
 #define LB 8            /* base panel width */
 #define LU_THREADS 1024
 #define TB 16           /* triangular-solve base */
@@ -99,6 +110,7 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
   __shared__ double s_prow[LB], s_crow[LB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+  LU_TSTAMP(0);
   double a[R][LB];
 #pragma unroll
   for (int s = 0; s < R; s++) {
@@ -132,12 +144,14 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
         const double v = fabs(a[s][j]);
         if (row < n32 && row >= col && v > best) { best = v; brow = row; }
       }
+      LU_TSTAMP(2 + 6 * j);
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         const double ov = __shfl_xor(best, off);
         const unsigned orow = __shfl_xor(brow, off);
         if (ov > best || (ov == best && orow < brow)) { best = ov; brow = orow; }
       }
+      LU_TSTAMP(3 + 6 * j);
       if (lane == 0) { s_val[wave] = best; s_row[wave] = brow; }
       __syncthreads();
       /* second level: lane k of every wave takes wave k's candidate, a 4-step butterfly finishes it (one LDS round
@@ -155,6 +169,7 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       piv = (unsigned)__builtin_amdgcn_readfirstlane((int)piv);
       if (piv == 0xffffffffu) piv = col;            /* NaN column: keep the diagonal row */
       if (tid == 0) ipiv[col] = (int)piv;
+      LU_TSTAMP(4 + 6 * j);
       /* publish the pivot row and the current row, then swap them */
       const unsigned own_p = (piv - j032) % NTH, slot_p = (piv - j032) / NTH;
       const unsigned own_c = (unsigned)j % NTH;       /* col - j0 = j < 1024: slot 0 */
@@ -169,6 +184,7 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
         for (int k = 0; k < LB; k++) s_crow[k] = a[0][k];
       }
       __syncthreads();
+      LU_TSTAMP(5 + 6 * j);
       if (piv != col) {
 #pragma unroll
         for (int s = 0; s < R; s++)
@@ -181,6 +197,7 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
           for (int k = 0; k < LB; k++) a[0][k] = s_prow[k];
         }
       }
+      LU_TSTAMP(6 + 6 * j);
       const double ajj = s_prow[j];
       if (ajj != 0.0) {                              /* lu.c:105 */
 #pragma unroll
@@ -196,11 +213,13 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      LU_TSTAMP(7 + 6 * j);
       /* s_val / s_prow are rewritten only after the next iteration's first barrier
          resp. between its two barriers: no third barrier needed */
     }
   }
 
+  LU_TSTAMP(60);
 #pragma unroll
   for (int s = 0; s < R; s++) {
     const size_t row = j0 + tid + (size_t)NTH * s;
@@ -214,6 +233,7 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
       for (int k = 0; k < LB; k++) if (k < w) p[k] = a[s][k];
     }
   }
+  LU_TSTAMP(61);
 }
 
 
@@ -454,6 +474,210 @@ lu_block_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int wb,
   }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Cooperative panel kernel (round 4): G = ceil(rows / 256) workgroups factor ONE 64-wide panel A[j0:n, j0:j0+wb] together.
+   A single workgroup cannot feed a tall panel (measured: loading 4096 rows x 64 B takes one CU 20 us -- ~200 outstanding
+   lines per microsecond --, a third of the 8-column base kernel's 63 us, the store another fifth), and the recursion between
+   8-column panels costs ~3500 launches per factorisation.  Here every thread keeps ONE row of the panel (64 doubles) in
+   registers for all 64 column steps, rows never move (each carries its POSITION, i.e. its row index after the reference's
+   swaps, lu.c:95-101; the copy-back writes a row where its position says), and a column step is
+       local candidate (DPP wave reduction, one barrier)  ->  ONE grid-wide exchange  ->  rank-1 update in registers.
+   Exchange: every workgroup publishes its candidate {|a|, position, the candidate row's 64 values} into its slot (parity
+   double-buffered) as 8-byte words {tag | 32 payload bits} with agent-scope stores; every workgroup polls ALL slots (the
+   rows speculatively with the headers: one memory round trip per column, no flag-then-data) and picks the same winner
+   with the reference's rule -- larger |a|, first position on ties, NaN never beats the diagonal row, a NaN diagonal keeps
+   itself (lu.c:82-93, strict '>').  tag = generation * 64 + column + 1; the generation counter is advanced by workgroup 0
+   when the panel is done, so a replayed graph never mistakes an old word for a new one.  Two slots per workgroup suffice: a
+   workgroup can only publish column j + 2 after every other one has published j + 1, i.e. has finished reading j.
+   Deadlock: the G <= 64 workgroups (one per CU, ~300 VGPRs) are co-resident; every poll loop is bounded and a time-out
+   raises a sticky abort word that ends all later waits at once (the host then reports GSL_EFAILED). */
+#define LC_W 64
+#define LC_ROWS 256
+#define LC_GMAX 64
+#define LC_SLOT_WORDS 136                      /* 128 row words + 3 header words, padded */
+#define LC_POLL_MAX (1 << 22)
+
+__device__ __forceinline__ void lc_better(double &k, unsigned &p, double ok, unsigned op)
+{
+  if (ok > k || (ok == k && op < p)) { k = ok; p = op; }
+}
+template <int CTRL, int RMASK>
+__device__ __forceinline__ void lc_dpp_step(double &k, unsigned &p)
+{
+  const int lo = __double2loint(k), hi = __double2hiint(k);
+  const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, RMASK, 0xF, false);
+  const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, RMASK, 0xF, false);
+  const unsigned op = (unsigned)__builtin_amdgcn_update_dpp((int)p, (int)p, CTRL, RMASK, 0xF, false);
+  lc_better(k, p, __hiloint2double(ohi, olo), op);
+}
+/* wave-wide argmax of (key, smaller position on ties); the result is uniform */
+__device__ __forceinline__ void lc_wave_argmax(double &k, unsigned &p)
+{
+  lc_dpp_step<0xB1, 0xF>(k, p);                /* quad_perm [1,0,3,2] */
+  lc_dpp_step<0x4E, 0xF>(k, p);                /* quad_perm [2,3,0,1] */
+  lc_dpp_step<0x141, 0xF>(k, p);               /* row_half_mirror */
+  lc_dpp_step<0x140, 0xF>(k, p);               /* row_mirror: all 16 lanes of a row agree */
+  lc_dpp_step<0x142, 0xA>(k, p);               /* row_bcast15 into rows 1, 3 */
+  lc_dpp_step<0x143, 0xC>(k, p);               /* row_bcast31 into rows 2, 3: lane 63 holds the wave's result */
+  const int lo = __builtin_amdgcn_readlane(__double2loint(k), 63), hi = __builtin_amdgcn_readlane(__double2hiint(k), 63);
+  k = __hiloint2double(hi, lo);
+  p = (unsigned)__builtin_amdgcn_readlane((int)p, 63);
+}
+
+struct LcShared {
+  double wrow[4][LC_W];                        /* the four waves' candidate rows */
+  double cand[4][LC_W];                        /* after the exchange: each wave's best polled row */
+  double wkey[4], ckey[4];
+  unsigned wpos[4], cpos[4];
+};
+
+template <int J>
+__device__ __forceinline__ void lc_step(double (&a)[LC_W], unsigned &pos, const bool valid, const unsigned j0, const int wb, LcShared &sh,
+                                        unsigned long long *__restrict__ slots, unsigned *__restrict__ ctl, const unsigned tagbase,
+                                        const unsigned G, int *__restrict__ ipiv, bool &dead)
+{
+  if constexpr (J < LC_W) {
+    if (J < wb) {                                           /* wb is uniform */
+      const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+      const unsigned c = j0 + (unsigned)J, tag = tagbase + (unsigned)J + 1u;
+      LC_TSTAMP(6 * J);
+      /* ---- local candidate ---- */
+      const double v = fabs(a[J]);
+      const bool active = valid && pos >= c;
+      double key = !active ? -2.0 : (pos == c ? (v != v ? INFINITY : v) : (v == v ? v : -1.0));
+      unsigned kp = active ? pos : 0xffffffffu;
+      const unsigned mypos = kp;
+      lc_wave_argmax(key, kp);
+      if (active && mypos == kp) {                          /* this wave's candidate row (positions are unique) */
+#pragma unroll
+        for (int k = 0; k < LC_W; k += 2) *reinterpret_cast<double2 *>(&sh.wrow[wave][k]) = make_double2(a[k], a[k + 1]);
+      }
+      if (lane == 0) { sh.wkey[wave] = key; sh.wpos[wave] = kp; }
+      __syncthreads();
+      LC_TSTAMP(6 * J + 1);
+      /* ---- publish the workgroup's candidate: wave 0 the row, wave 1 the header (the other waves go straight to the poll) ---- */
+      if (wave < 2) {
+        double bk = sh.wkey[0]; unsigned bp = sh.wpos[0]; int bw = 0;
+#pragma unroll
+        for (int w = 1; w < 4; w++) { const double ok = sh.wkey[w]; const unsigned op = sh.wpos[w]; if (ok > bk || (ok == bk && op < bp)) { bk = ok; bp = op; bw = w; } }
+        unsigned long long *slot = slots + ((size_t)(J & 1) * LC_GMAX + blockIdx.x) * LC_SLOT_WORDS;
+        const unsigned long long th = (unsigned long long)tag << 32;
+        if (wave == 0) {
+          const double x = sh.wrow[bw][lane];
+          __hip_atomic_store(slot + 2 * lane, th | (unsigned)__double2loint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot + 2 * lane + 1, th | (unsigned)__double2hiint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (wave == 1 && lane < 3) {
+          const unsigned w32 = lane == 0 ? (unsigned)__double2loint(bk) : (lane == 1 ? (unsigned)__double2hiint(bk) : bp);
+          __hip_atomic_store(slot + 128 + lane, th | w32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      LC_TSTAMP(6 * J + 2);
+      /* ---- poll every slot (wave w takes slots w, w + 4, ...; four at a time, all their loads in flight together):
+              headers and rows in the same round trip.  (Every wave polling ALL slots itself, which saves the second
+              barrier, was slower: 327 vs 257 us per panel -- 4 x the polling traffic per CU.) ---- */
+      double gk = -3.0, grow = 0.0;
+      unsigned gp = 0xffffffffu;
+      for (unsigned gb = (unsigned)wave; gb < G; gb += 16) {
+        unsigned long long w0[4], w1[4], wh[4];
+        int spins = 0;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const unsigned g = gb + 4u * q;
+            if (g < G) {
+              const unsigned long long *slot = slots + ((size_t)(J & 1) * LC_GMAX + g) * LC_SLOT_WORDS;
+              w0[q] = __hip_atomic_load(slot + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              w1[q] = __hip_atomic_load(slot + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              wh[q] = __hip_atomic_load(slot + 128 + (lane < 3 ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (gb + 4u * q < G) ok = ok && (unsigned)(w0[q] >> 32) == tag && (unsigned)(w1[q] >> 32) == tag && (unsigned)(wh[q] >> 32) == tag;
+          if (__all(ok) || dead) break;
+          if (++spins > LC_POLL_MAX || ((spins & 255) == 0 && __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            dead = true;
+            if (lane == 0) __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (gb + 4u * q < G) {
+            const int klo = __builtin_amdgcn_readlane((int)(unsigned)wh[q], 0), khi = __builtin_amdgcn_readlane((int)(unsigned)wh[q], 1);
+            const double ok_ = __hiloint2double(khi, klo);
+            const unsigned op_ = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wh[q], 2);
+            if (ok_ > gk || (ok_ == gk && op_ < gp)) { gk = ok_; gp = op_; grow = __hiloint2double((int)(unsigned)w1[q], (int)(unsigned)w0[q]); }
+          }
+      }
+      LC_TSTAMP(6 * J + 3);
+      sh.cand[wave][lane] = grow;
+      if (lane == 0) { sh.ckey[wave] = gk; sh.cpos[wave] = gp; }
+      __syncthreads();
+      double bk = sh.ckey[0]; unsigned piv = sh.cpos[0]; int bw = 0;
+#pragma unroll
+      for (int w = 1; w < 4; w++) { const double ok = sh.ckey[w]; const unsigned op = sh.cpos[w]; if (ok > bk || (ok == bk && op < piv)) { bk = ok; piv = op; bw = w; } }
+      if (piv == 0xffffffffu) piv = c;                      /* cannot happen (the diagonal row is always a candidate) */
+      if (blockIdx.x == 0 && tid == 0) ipiv[c] = (int)piv;
+      LC_TSTAMP(6 * J + 4);
+      /* ---- the swap, in positions ---- */
+      if (valid) { if (pos == piv) pos = c; else if (pos == c) pos = piv; }
+      const double *prow = sh.cand[bw];
+      const double ajj = prow[J];
+      if (valid && pos > c && ajj != 0.0) {                 /* lu.c:105 */
+        const double l = a[J] / ajj;
+        a[J] = l;
+#pragma unroll
+        for (int k = J + 1; k < LC_W; k++) a[k] = a[k] - l * prow[k];
+      }
+    }
+    LC_TSTAMP(6 * J + 5);
+    lc_step<J + 1>(a, pos, valid, j0, wb, sh, slots, ctl, tagbase, G, ipiv, dead);
+  }
+}
+
+__global__ void __launch_bounds__(LC_ROWS)
+lu_coop_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int wb, int *__restrict__ ipiv,
+               unsigned long long *__restrict__ slots, unsigned *__restrict__ ctl)
+{
+  __shared__ LcShared sh;
+  const int tid = threadIdx.x;
+  const unsigned G = gridDim.x;
+  const unsigned gen = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* stable until workgroup 0 ends */
+  const unsigned tagbase = gen * 64u;
+  const size_t row = j0 + (size_t)blockIdx.x * LC_ROWS + tid;
+  const bool valid = row < n;
+  unsigned pos = (unsigned)row;
+  double a[LC_W];
+  if (valid) {
+    const double *p = A + row * lda + j0;                   /* 16-byte aligned: lda even, j0 even (host checks) */
+#pragma unroll
+    for (int k = 0; k < LC_W; k += 2) {
+      if (k + 1 < wb) { const double2 t = *reinterpret_cast<const double2 *>(p + k); a[k] = t.x; a[k + 1] = t.y; }
+      else { a[k] = k < wb ? p[k] : 0.0; a[k + 1] = 0.0; }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < LC_W; k++) a[k] = 0.0;
+  }
+  bool dead = false;
+  LC_TSTAMP(384);
+  lc_step<0>(a, pos, valid, (unsigned)j0, wb, sh, slots, ctl, tagbase, G, ipiv, dead);
+  /* every workgroup has published the last column, hence loaded its rows: positions can be written over them */
+  if (valid) {
+    double *p = A + (size_t)pos * lda + j0;
+#pragma unroll
+    for (int k = 0; k < LC_W; k += 2) {
+      if (k + 1 < wb) *reinterpret_cast<double2 *>(p + k) = make_double2(a[k], a[k + 1]);
+      else if (k < wb) p[k] = a[k];
+    }
+  }
+  LC_TSTAMP(385);
+  if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* apply the row interchanges k = k0..k1-1 (row k <-> ipiv[k]) to columns c0..c0+nc-1 */
 __global__ void __launch_bounds__(256)
 laswp_kernel(double *__restrict__ A, size_t lda, size_t c0, size_t nc, const int *__restrict__ ipiv, size_t k0, size_t k1)
@@ -498,17 +722,103 @@ trsm_unit_lower_base_kernel(double *__restrict__ A, size_t lda, size_t r0, int n
   for (int r = 0; r < TB; r++) if (r < nb) col[(size_t)r * lda] = x[r];
 }
 
+/* 64-row base of the same solve (round 4): X = L^-1 B for a unit-lower 64 x 64 block, one column of B per thread, 16 rows at
+   a time in registers: a block first takes the updates of the solved values above it (kept in LDS, one runtime loop with 16
+   independent FMAs per solved value), then its own 16 x 16 triangle.  L transposed in LDS: a step reads its column of
+   multipliers as uniform 16-byte words.  One launch instead of the seven (four 16-row bases + three products) the 16-row
+   recursion spent on a 64-row block: ~1470 -> ~320 launches for the U12 solves of an N = 4096 factorisation.  (All 64 values
+   in registers with the solve fully unrolled: the scheduler hoists the 2016 LDS reads, 15 KB of scratch per lane, 259 us.) */
+#define TB64 64
+__global__ void __launch_bounds__(64)
+trsm_unit_lower64_kernel(double *__restrict__ A, size_t lda, size_t r0, int nb, size_t c0, size_t nc)
+{
+  __shared__ double sLt[TB64][TB64];                     /* sLt[k][r] = L[r][k], r > k */
+  __shared__ double xs[TB64][64];                        /* solved values of this workgroup's 64 columns */
+  const int tid = threadIdx.x;
+  const size_t c = (size_t)blockIdx.x * 64 + tid;
+  const bool live = c < nc;
+  double *col = A + r0 * lda + c0 + (live ? c : 0);
+  /* this thread's whole column, requested before anything else (four dependent load latencies otherwise) */
+  double xr[TB64 / 16][16];
+#pragma unroll
+  for (int rb = 0; rb < TB64 / 16; rb++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) xr[rb][r] = (live && rb * 16 + r < nb) ? col[(size_t)(rb * 16 + r) * lda] : 0.0;
+  }
+  /* L transposed into LDS: lane = row (its 64 multipliers are contiguous in memory), so the LDS writes of a step go to
+     consecutive words (lane = k would put all 64 lanes on one bank) */
+  {
+    const double *lrow = A + (r0 + (tid < nb ? tid : 0)) * lda + r0;
+#pragma unroll 8
+    for (int k = 0; k < TB64; k++) sLt[k][tid] = (tid < nb && k < tid) ? lrow[k] : 0.0;
+  }
+  __syncthreads();
+  if (!live) return;
+#pragma unroll
+  for (int rb = 0; rb < TB64 / 16; rb++) {
+    if (rb * 16 < nb) {
+      double (&x)[16] = xr[rb];
+#pragma unroll 4
+      for (int k = 0; k < rb * 16; k++) {                /* the blocks above: 16 updates per solved value (4 in flight) */
+        const double xk = xs[k][tid];
+        const double *l = &sLt[k][rb * 16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = fma(-l[r], xk, x[r]);
+      }
+#pragma unroll
+      for (int k = 0; k < 15; k++) {                     /* this block's 16 x 16 triangle */
+        const double *l = &sLt[rb * 16 + k][rb * 16];
+#pragma unroll
+        for (int r = k + 1; r < 16; r++) x[r] = fma(-l[r], x[k], x[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        xs[rb * 16 + r][tid] = x[r];
+        if (rb * 16 + r < nb && rb * 16 + r > 0) col[(size_t)(rb * 16 + r) * lda] = x[r];     /* row 0 is unchanged */
+      }
+    }
+  }
+}
+
+/* the interchanges of ONE 64-wide panel (k0 <= k < k1) applied to every column outside it, [0, k0) and [k1', n): run right
+   after the panel kernel ("eager"), so a thread's dependent chain is 64 swaps; the recursion's own calls walked up to 2048
+   swaps per thread (408 us for the top level: 160 GB/s).  Equivalent: the columns to the right are not touched by anything
+   else before the swaps the recursion would have applied to them. */
+__global__ void __launch_bounds__(64)
+laswp_outside_kernel(double *__restrict__ A, size_t lda, size_t n, size_t pc0, size_t pw, const int *__restrict__ ipiv, size_t k0, size_t k1)
+{
+  size_t c = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (c >= n - pw) return;
+  if (c >= pc0) c += pw;                                  /* skip the panel's own columns */
+  double *col = A + c;
+  for (size_t k = k0; k < k1; k++) {
+    const size_t p = (size_t)ipiv[k];
+    if (p != k) {
+      const double a = col[k * lda], b = col[p * lda];
+      col[k * lda] = b; col[p * lda] = a;
+    }
+  }
+}
+
 static int trsm_unit_lower(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t r0, size_t nb, size_t c0, size_t nc)
 {
   if (nb == 0 || nc == 0) return ST_SUCCESS;
+  static const bool no64 = getenv("GSL_SINTERP_NO_TRSM64") && getenv("GSL_SINTERP_NO_TRSM64")[0] == '1';
+  if (!no64 && nb <= TB64 && nb > TB) {
+    hipLaunchKernelGGL(trsm_unit_lower64_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, ctx->stream, A, lda,
+                       r0, (int)nb, c0, nc);
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
   if (nb <= TB) {
     hipLaunchKernelGGL(trsm_unit_lower_base_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, A, lda,
                        r0, (int)nb, c0, nc);
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }
-  size_t n1 = ((nb / 2 + TB - 1) / TB) * TB;
-  if (n1 >= nb) n1 = nb - TB;
+  const size_t tb = (!no64 && nb > TB64) ? TB64 : TB;
+  size_t n1 = ((nb / 2 + tb - 1) / tb) * tb;
+  if (n1 >= nb) n1 = nb - tb;
   int st = trsm_unit_lower(ctx, A, lda, r0, n1, c0, nc);
   if (st) return st;
   /* B2 -= L21 * X1 :  L21 = A[r0+n1 : r0+nb, r0 : r0+n1],  X1 = A[r0 : r0+n1, c0 : c0+nc] */
@@ -518,8 +828,16 @@ static int trsm_unit_lower(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size
   return trsm_unit_lower(ctx, A, lda, r0 + n1, nb - n1, c0, nc);
 }
 
-static int lu_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, size_t j0, size_t w, int *d_ipiv)
+/* the cooperative panel kernel applies: buffers in place, aligned rows, at most LC_GMAX workgroups */
+static bool lu_coop_ok(const gsl_sinterp_hip_ctx *ctx, size_t lda, size_t n, size_t j0)
 {
+  static const bool off = getenv("GSL_SINTERP_NO_LU_COOP") && getenv("GSL_SINTERP_NO_LU_COOP")[0] == '1';
+  return !off && ctx->d_lu_coop != NULL && (lda & 1) == 0 && (j0 & 1) == 0 && n - j0 <= (size_t)LC_GMAX * LC_ROWS;
+}
+
+static int lu_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, size_t j0, size_t w, int *d_ipiv, bool eager)
+{
+  const size_t kend = j0 + w < n ? j0 + w : n;
   const size_t prow = n - j0;
   /* measured on MI355X: the single-workgroup block kernel wins while the panel is short
      (<= 1024 rows: its dependent global round trips are few); taller panels go through the
@@ -535,6 +853,18 @@ static int lu_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, s
       hipLaunchKernelGGL(lu_block_kernel<4>, dim3(1), dim3(BT), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
     else
       hipLaunchKernelGGL(lu_block_kernel<8>, dim3(1), dim3(BT), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv);
+    if (eager && n > w)
+      hipLaunchKernelGGL(laswp_outside_kernel, dim3((unsigned)((n - w + 63) / 64)), dim3(64), 0, ctx->stream, A, lda, n, j0, w, d_ipiv, j0, kend);
+    LAUNCH_CHECK(ctx);
+    return ST_SUCCESS;
+  }
+  /* tall 64-wide panels: the cooperative kernel (one 64-column step of the recursion = one launch) */
+  if (w <= LC_W && lu_coop_ok(ctx, lda, n, j0)) {          /* (the shorter ones went to the block kernel above) */
+    const unsigned G = (unsigned)((prow + LC_ROWS - 1) / LC_ROWS);
+    hipLaunchKernelGGL(lu_coop_kernel, dim3(G), dim3(LC_ROWS), 0, ctx->stream, A, lda, n, j0, (int)w, d_ipiv,
+                       (unsigned long long *)((char *)ctx->d_lu_coop + 64), (unsigned *)ctx->d_lu_coop);
+    if (eager && n > w)
+      hipLaunchKernelGGL(laswp_outside_kernel, dim3((unsigned)((n - w + 63) / 64)), dim3(64), 0, ctx->stream, A, lda, n, j0, w, d_ipiv, j0, kend);
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }
@@ -559,24 +889,28 @@ static int lu_panel(gsl_sinterp_hip_ctx *ctx, double *A, size_t lda, size_t n, s
     LAUNCH_CHECK(ctx);
     return ST_SUCCESS;
   }
-  const size_t unit = (prow <= block_rows && prow <= (size_t)BT * 8 && w > BW) ? BW : LB;   /* split on block-kernel boundaries */
+  const size_t unit = (w > BW && ((prow <= block_rows && prow <= (size_t)BT * 8) || lu_coop_ok(ctx, lda, n, j0))) ? BW : LB;   /* split on 64-wide panel boundaries */
   size_t w1 = ((w / 2 + unit - 1) / unit) * unit;
   if (w1 >= w) w1 = w - unit;
   const size_t w2 = w - w1, c1 = j0 + w1;
-  int st = lu_panel(ctx, A, lda, n, j0, w1, d_ipiv);
+  int st = lu_panel(ctx, A, lda, n, j0, w1, d_ipiv, eager);
   if (st) return st;
-  hipLaunchKernelGGL(laswp_kernel, dim3((unsigned)((w2 + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, c1, w2, d_ipiv, j0, c1);
-  LAUNCH_CHECK(ctx);
+  if (!eager) {
+    hipLaunchKernelGGL(laswp_kernel, dim3((unsigned)((w2 + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, c1, w2, d_ipiv, j0, c1);
+    LAUNCH_CHECK(ctx);
+  }
   st = trsm_unit_lower(ctx, A, lda, j0, w1, c1, w2);             /* U12 = L11^-1 A12 */
   if (st) return st;
   st = sinterp_gemm_minus(ctx, n - c1, w2, w1, A + c1 * lda + j0, lda, A + j0 * lda + c1, lda, 1,
                           A + c1 * lda + c1, lda, 0);           /* A22 -= A21 U12 */
   if (st) return st;
-  st = lu_panel(ctx, A, lda, n, c1, w2, d_ipiv);
+  st = lu_panel(ctx, A, lda, n, c1, w2, d_ipiv, eager);
   if (st) return st;
-  hipLaunchKernelGGL(laswp_kernel, dim3((unsigned)((w1 + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, j0, w1, d_ipiv, c1,
-                     c1 + w2 < n ? c1 + w2 : n);
-  LAUNCH_CHECK(ctx);
+  if (!eager) {
+    hipLaunchKernelGGL(laswp_kernel, dim3((unsigned)((w1 + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, j0, w1, d_ipiv, c1,
+                       c1 + w2 < n ? c1 + w2 : n);
+    LAUNCH_CHECK(ctx);
+  }
   return ST_SUCCESS;
 }
 
@@ -593,13 +927,20 @@ extern "C" int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, dou
   int replayed = 0;
   int st = sinterp_streamk_prepare(ctx);               /* the N.N updates run on the stream-K kernel (buffers: outside capture) */
   if (st) return st;
+  if (!ctx->d_lu_coop) {                               /* [generation, abort | slots], zeroed once: tags start at 1 */
+    const size_t bytes = 64 + (size_t)2 * LC_GMAX * LC_SLOT_WORDS * sizeof(unsigned long long);
+    HIP_OK(ctx, hipMalloc(&ctx->d_lu_coop, bytes));
+    HIP_OK(ctx, hipMemset(ctx->d_lu_coop, 0, bytes));
+  }
   st = sinterp_graph_try_launch(ctx, 1, n, lda, d_a, d_perm, &replayed);
   if (st) return st;
   if (!replayed) {
     hipStream_t saved;
     st = sinterp_capture_begin(ctx, &saved);
     if (st) return st;
-    st = lu_panel(ctx, d_a, lda, n, 0, n, d_perm);                /* d_perm holds LAPACK-style ipiv for now */
+    /* every leaf a 64-wide panel (block or cooperative kernel): its interchanges go to the other columns right away */
+    const bool eager = lu_coop_ok(ctx, lda, n, 0);
+    st = lu_panel(ctx, d_a, lda, n, 0, n, d_perm, eager);         /* d_perm holds LAPACK-style ipiv for now */
     int st2 = sinterp_capture_end(ctx, saved, 1, n, lda, d_a, d_perm);
     if (st) return st;
     if (st2) return st2;
@@ -609,6 +950,13 @@ extern "C" int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, dou
   int *h_perm = (int *)malloc(n * sizeof(int));
   if (!h_ipiv || !h_perm) { free(h_ipiv); free(h_perm); return sinterp_fail(ctx, ST_ENOMEM, "lu_decomp: host buffers", hipSuccess, __FILE__, __LINE__); }
   hipError_t e = hipStreamSynchronize(ctx->stream);
+  unsigned h_ctl[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpy(h_ctl, ctx->d_lu_coop, sizeof h_ctl, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && h_ctl[1] != 0) {             /* a grid-wide exchange timed out: the result is not a factorisation */
+    (void)hipMemset((char *)ctx->d_lu_coop + 4, 0, 4);
+    free(h_ipiv); free(h_perm);
+    return sinterp_fail(ctx, ST_EFAILED, "lu_decomp: the cooperative panel kernel timed out waiting for a workgroup", hipSuccess, __FILE__, __LINE__);
+  }
   if (e == hipSuccess) e = hipMemcpy(h_ipiv, d_perm, n * sizeof(int), hipMemcpyDeviceToHost);
   int sign = 1;
   if (e == hipSuccess) {

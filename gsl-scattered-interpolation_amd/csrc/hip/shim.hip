@@ -78,6 +78,7 @@ extern "C" void gsl_sinterp_hip_ctx_destroy(gsl_sinterp_hip_ctx *ctx)
   if (ctx->d_sk_flags) (void)hipFree(ctx->d_sk_flags);
   if (ctx->d_tf) (void)hipFree(ctx->d_tf);
   if (ctx->d_xq) (void)hipFree(ctx->d_xq);
+  if (ctx->d_lu_coop) (void)hipFree(ctx->d_lu_coop);
   if (ctx->d_jumpt) (void)hipFree(ctx->d_jumpt);
   if (ctx->d_lw_a) (void)hipFree(ctx->d_lw_a);
   if (ctx->d_lw_lines) (void)hipFree(ctx->d_lw_lines);

@@ -89,7 +89,7 @@ def test_hilbert_known_answers(pkg, n):
     assert ok(d_x.cpu().numpy(), spec["lu_eps_mult"] * EPS if "lu_eps_mult" in spec else spec["lu_abs_tol"])
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 33, 100, 255, 1024, 2000, 2048])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 33, 100, 255, 1024, 1100, 2000, 2048, 3000])    # > 1024 rows: cooperative 64-wide panels
 def test_lu_decomp_and_solve(pkg, orc, n):
     rng = np.random.default_rng(n)
     a = rng.standard_normal((n, n))
