@@ -511,16 +511,17 @@ def rooflines(cfg, name, n, dim, m_rank, ph, extra=None, gemm=None):
     if cfg["kind"] == "bary":
         t = ph["bary_eval"] * 1e-3
         by = 28.0 * m_rank                               # 16 B target in, 8 B value + 4 B leaf out
-        pmc = committed_pmc(name, "bary_walk_kernel")
-        res["roofline"] = {"kernel": "bary_walk_kernel (+ start / finish kernels, cell sort / gather / un-sort of the targets)", "bound": "hbm",
+        pmc = committed_pmc(name, "leafwalk_kernel")
+        res["roofline"] = {"kernel": "leafwalk_kernel (+ exact kernel on the ~1 % the margin test leaves, two-level reorder / un-sort of the targets)", "bound": "hbm",
                            "achieved": round(by / t / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 6),
                            "traffic": pmc["hbm_traffic_bytes_per_launch"] if pmc and "hbm_traffic_bytes_per_launch" in pmc else None,
                            "traffic_source": pmc["source"] if pmc else None,
-                           "note": "the algorithmic HBM stream is 28 B/target; a third of the step is the two-level reorder of the "
-                                   "targets (five streaming passes, 104 B/target at ~3.3 TB/s) and the one random gather of the "
-                                   "un-sort, the rest the DAG walk, which is bound by the latency of its dependent 64-byte "
-                                   "gathers (records resident in L2 / Infinity Cache), not by HBM"}
+                           "note": "the algorithmic HBM stream is 28 B/target; of the 1.18 ms step 0.35 is the two-level reorder of the "
+                                   "targets (five streaming passes, 104 B/target at ~3.3 TB/s), 0.14 the random gather of the un-sort, "
+                                   "0.56 the certified leaf walk (0.38 the walk over the leaves' adjacency from the grid seed: latency of "
+                                   "dependent 64-byte gathers from L2 / Infinity Cache; 0.18 the margin test against the leaf's ~13 lines: "
+                                   "per-lane load rate), 0.09 the exact DAG kernel on the ~1 % of targets the margin leaves -- not HBM"}
         res["eval_only_mpts"] = round(m_rank / t / 1e6, 3)
         return res
     route = (extra or {}).get("route", {}).get("route", 1)

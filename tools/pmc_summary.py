@@ -33,7 +33,7 @@ for d in sorted(glob.glob(os.path.join(root, "*_*"))):
             name = re.sub(r"\(.*$", "", name)
             vals[(cfg, name)][ctr].append(float(r["Counter_Value"]))
 
-KEEP = ("gemm_minus_streamk_kernel", "rbf_eval", "bary_eval_kernel", "bary_walk_kernel", "bary_start_kernel", "bary_finish_kernel", "walk_pack_kernel", "rbf_fill_kernel", "trsv_dataflow_kernel", "chol_trsm128_kernel",
+KEEP = ("gemm_minus_streamk_kernel", "rbf_eval", "bary_eval_kernel", "leafwalk_kernel", "lw_", "bary_walk_kernel", "bary_start_kernel", "bary_finish_kernel", "walk_pack_kernel", "rbf_fill_kernel", "trsv_dataflow_kernel", "chol_trsm128_kernel",
         "chol_diag128_kernel", "cell_", "tl_", "tree_", "unsort_", "jump_build_kernel", "centre_pack_kernel")
 counters = collections.defaultdict(dict)
 rows, traffic = [], collections.defaultdict(dict)
