@@ -130,6 +130,8 @@ struct SinterpExclusive {      /* RAII form: every return path of an entry point
 /* rbf.hip: the fill with the option of writing the tiles on / below the diagonal only */
 int sinterp_rbf_fill_ex(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const double *d_x, size_t n, int dim, size_t xtda,
                         double *d_phi, size_t lda, int lower_only);
+int sinterp_tps_fill_shifted(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, int dim, size_t xtda, double *d_phi, size_t lda,
+                             const double *d_Pk, int k, double cmul, unsigned long long *d_norm);
 
 /* grow-only workspace owned by the context */
 int sinterp_workspace(gsl_sinterp_hip_ctx *ctx, size_t bytes, void **out);

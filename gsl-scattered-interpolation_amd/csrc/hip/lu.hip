@@ -53,7 +53,8 @@ lu_base_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int w, i
     double best = -1.0;
     unsigned long long brow = ~0ULL;
     for (size_t i = col + tid; i < n; i += LU_THREADS) {
-      const double v = fabs(A[i * lda + col]);
+      double v = fabs(A[i * lda + col]);
+      if (i == col && v != v) v = INFINITY;        /* a NaN diagonal keeps itself: nothing compares greater (lu.c:82-93) */
       if (v > best) { best = v; brow = i; }        /* ascending i per thread: keeps the first */
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -141,7 +142,8 @@ lu_base_reg_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int 
 #pragma unroll
       for (int s = 0; s < R; s++) {
         const unsigned row = rbase + (unsigned)NTH * s;
-        const double v = fabs(a[s][j]);
+        double v = fabs(a[s][j]);
+        if (row == col && v != v) v = INFINITY;     /* a NaN diagonal keeps itself (lu.c:82-93) */
         if (row < n32 && row >= col && v > best) { best = v; brow = row; }
       }
       LU_TSTAMP(2 + 6 * j);
@@ -303,7 +305,8 @@ lu_block_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int wb,
 #pragma unroll
         for (int s = 0; s < R; s++) {
           const size_t row = j0 + tid + (size_t)BT * s;
-          const double v = fabs(a[s][j]);
+          double v = fabs(a[s][j]);
+          if (pos[s] == col && v != v) v = INFINITY;   /* a NaN diagonal keeps itself (lu.c:82-93) */
           const bool act = row < n && !((retired >> s) & 1u);
           if (act && (v > best || (v == best && pos[s] < bpos))) { best = v; bpos = pos[s]; }
         }
@@ -532,11 +535,16 @@ struct LcShared {
 };
 
 template <int J>
-__device__ __forceinline__ void lc_step(double (&a)[LC_W], unsigned &pos, const bool valid, const unsigned j0, const int wb, LcShared &sh,
+__device__ __forceinline__ void lc_step(double (&a)[LC_W], unsigned &pos, const bool valid, const unsigned j0, const int wb, LcShared &sh, const unsigned bid,
                                         unsigned long long *__restrict__ slots, unsigned *__restrict__ ctl, const unsigned tagbase,
                                         const unsigned G, int *__restrict__ ipiv, bool &dead)
 {
   if constexpr (J < LC_W) {
+    /* Agent scope throughout.  Tried: all workers on ONE XCD (every 8th block of an 8 x larger grid works; XCC_IDs exchanged and
+       compared at kernel start) with workgroup-scope (sc0) stores / loads so that the XCD's L2 would be the point of coherence
+       instead of memory -- the polls never saw the other CUs' stores (with and without `buffer_inv sc0` before each poll): every
+       exchange timed out.  Removed. */
+    constexpr int SC = __HIP_MEMORY_SCOPE_AGENT;
     if (J < wb) {                                           /* wb is uniform */
       const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
       const unsigned c = j0 + (unsigned)J, tag = tagbase + (unsigned)J + 1u;
@@ -560,15 +568,15 @@ __device__ __forceinline__ void lc_step(double (&a)[LC_W], unsigned &pos, const 
         double bk = sh.wkey[0]; unsigned bp = sh.wpos[0]; int bw = 0;
 #pragma unroll
         for (int w = 1; w < 4; w++) { const double ok = sh.wkey[w]; const unsigned op = sh.wpos[w]; if (ok > bk || (ok == bk && op < bp)) { bk = ok; bp = op; bw = w; } }
-        unsigned long long *slot = slots + ((size_t)(J & 1) * LC_GMAX + blockIdx.x) * LC_SLOT_WORDS;
+        unsigned long long *slot = slots + ((size_t)(J & 1) * LC_GMAX + bid) * LC_SLOT_WORDS;
         const unsigned long long th = (unsigned long long)tag << 32;
         if (wave == 0) {
           const double x = sh.wrow[bw][lane];
-          __hip_atomic_store(slot + 2 * lane, th | (unsigned)__double2loint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(slot + 2 * lane + 1, th | (unsigned)__double2hiint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot + 2 * lane, th | (unsigned)__double2loint(x), __ATOMIC_RELAXED, SC);
+          __hip_atomic_store(slot + 2 * lane + 1, th | (unsigned)__double2hiint(x), __ATOMIC_RELAXED, SC);
         } else if (wave == 1 && lane < 3) {
           const unsigned w32 = lane == 0 ? (unsigned)__double2loint(bk) : (lane == 1 ? (unsigned)__double2hiint(bk) : bp);
-          __hip_atomic_store(slot + 128 + lane, th | w32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot + 128 + lane, th | w32, __ATOMIC_RELAXED, SC);
         }
       }
       LC_TSTAMP(6 * J + 2);
@@ -587,9 +595,9 @@ __device__ __forceinline__ void lc_step(double (&a)[LC_W], unsigned &pos, const 
             const unsigned g = gb + 4u * q;
             if (g < G) {
               const unsigned long long *slot = slots + ((size_t)(J & 1) * LC_GMAX + g) * LC_SLOT_WORDS;
-              w0[q] = __hip_atomic_load(slot + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              w1[q] = __hip_atomic_load(slot + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              wh[q] = __hip_atomic_load(slot + 128 + (lane < 3 ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              w0[q] = __hip_atomic_load(slot + 2 * lane, __ATOMIC_RELAXED, SC);
+              w1[q] = __hip_atomic_load(slot + 2 * lane + 1, __ATOMIC_RELAXED, SC);
+              wh[q] = __hip_atomic_load(slot + 128 + (lane < 3 ? lane : 0), __ATOMIC_RELAXED, SC);
             }
           }
 #pragma unroll
@@ -620,7 +628,7 @@ __device__ __forceinline__ void lc_step(double (&a)[LC_W], unsigned &pos, const 
 #pragma unroll
       for (int w = 1; w < 4; w++) { const double ok = sh.ckey[w]; const unsigned op = sh.cpos[w]; if (ok > bk || (ok == bk && op < piv)) { bk = ok; piv = op; bw = w; } }
       if (piv == 0xffffffffu) piv = c;                      /* cannot happen (the diagonal row is always a candidate) */
-      if (blockIdx.x == 0 && tid == 0) ipiv[c] = (int)piv;
+      if (bid == 0 && tid == 0) ipiv[c] = (int)piv;
       LC_TSTAMP(6 * J + 4);
       /* ---- the swap, in positions ---- */
       if (valid) { if (pos == piv) pos = c; else if (pos == c) pos = piv; }
@@ -634,7 +642,7 @@ __device__ __forceinline__ void lc_step(double (&a)[LC_W], unsigned &pos, const 
       }
     }
     LC_TSTAMP(6 * J + 5);
-    lc_step<J + 1>(a, pos, valid, j0, wb, sh, slots, ctl, tagbase, G, ipiv, dead);
+    lc_step<J + 1>(a, pos, valid, j0, wb, sh, bid, slots, ctl, tagbase, G, ipiv, dead);
   }
 }
 
@@ -644,10 +652,10 @@ lu_coop_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int wb, 
 {
   __shared__ LcShared sh;
   const int tid = threadIdx.x;
-  const unsigned G = gridDim.x;
+  const unsigned G = gridDim.x, bid = blockIdx.x;
   const unsigned gen = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* stable until workgroup 0 ends */
   const unsigned tagbase = gen * 64u;
-  const size_t row = j0 + (size_t)blockIdx.x * LC_ROWS + tid;
+  const size_t row = j0 + (size_t)bid * LC_ROWS + tid;
   const bool valid = row < n;
   unsigned pos = (unsigned)row;
   double a[LC_W];
@@ -664,7 +672,7 @@ lu_coop_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int wb, 
   }
   bool dead = false;
   LC_TSTAMP(384);
-  lc_step<0>(a, pos, valid, (unsigned)j0, wb, sh, slots, ctl, tagbase, G, ipiv, dead);
+  lc_step<0>(a, pos, valid, (unsigned)j0, wb, sh, bid, slots, ctl, tagbase, G, ipiv, dead);
   /* every workgroup has published the last column, hence loaded its rows: positions can be written over them */
   if (valid) {
     double *p = A + (size_t)pos * lda + j0;
@@ -675,7 +683,7 @@ lu_coop_kernel(double *__restrict__ A, size_t lda, size_t n, size_t j0, int wb, 
     }
   }
   LC_TSTAMP(385);
-  if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bid == 0 && tid == 0) __hip_atomic_store(ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* apply the row interchanges k = k0..k1-1 (row k <-> ipiv[k]) to columns c0..c0+nc-1 */
@@ -931,6 +939,8 @@ extern "C" int gsl_sinterp_hip_lu_decomp(gsl_sinterp_hip_ctx *ctx, size_t n, dou
     const size_t bytes = 64 + (size_t)2 * LC_GMAX * LC_SLOT_WORDS * sizeof(unsigned long long);
     HIP_OK(ctx, hipMalloc(&ctx->d_lu_coop, bytes));
     HIP_OK(ctx, hipMemset(ctx->d_lu_coop, 0, bytes));
+    const unsigned gen0 = 1;                             /* tag 0 = never written */
+    HIP_OK(ctx, hipMemcpy(ctx->d_lu_coop, &gen0, sizeof gen0, hipMemcpyHostToDevice));
   }
   st = sinterp_graph_try_launch(ctx, 1, n, lda, d_a, d_perm, &replayed);
   if (st) return st;

@@ -122,9 +122,13 @@ __device__ __forceinline__ void load_tables(double *s_t0, double *s_lt, int kind
 
 /* ------------------------------------------------------------------------ */
 /* fill: block = 256 threads -> 16 rows x 128 cols, 2 columns (16 B) per lane */
-template <int KIND, int DIM>
+/* SHIFT (thin-plate spline, round 4): the entry leaves as Phi_ij + s sum_a P_a[i] P_a[j] with s = cmul |Phi|_inf / n read from
+   norm_bits (tps_rownorm_kernel) -- the shifted SPD matrix of solve.hip in ONE pass over HBM; until round 3 the plain fill was
+   followed by a read of the whole matrix for its norm and a read-modify-write for the shift (61 + 61 us at N = 4096). */
+template <int KIND, int DIM, bool SHIFT = false>
 __global__ void __launch_bounds__(256)
-rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, double *__restrict__ phi, size_t lda, int lower_only)
+rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, double *__restrict__ phi, size_t lda, int lower_only,
+                const double *__restrict__ Pk = nullptr, int pk = 0, double cmul = 0.0, const unsigned long long *__restrict__ norm_bits = nullptr)
 {
   /* lower_only: tiles that lie entirely above the diagonal are not written (the Cholesky route reads the lower
      triangle only; half of the HBM writes of the fill) */
@@ -141,6 +145,17 @@ rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
   double xa[DIM], xb[DIM];
 #pragma unroll
   for (int c = 0; c < DIM; c++) { xa[c] = x[j0 * xtda + c]; xb[c] = two ? x[(j0 + 1) * xtda + c] : 0.0; }
+  double pja[4] = {0, 0, 0, 0}, pjb[4] = {0, 0, 0, 0}, pir[4][4] = {{0}}, sh = 0.0;
+  if (SHIFT) {
+    sh = cmul * __longlong_as_double((long long)*norm_bits) / (double)n;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+      if (a < pk) { pja[a] = Pk[(size_t)a * n + j0]; pjb[a] = two ? Pk[(size_t)a * n + j0 + 1] : 0.0; }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int a = 0; a < 4; a++) pir[r][a] = (a < pk && ibase + r < n) ? Pk[(size_t)a * n + ibase + r] : 0.0;   /* uniform over the wave; all in flight before the rows */
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const size_t i = ibase + r;
@@ -155,6 +170,13 @@ rbf_fill_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda
     double va = phi_r2<KIND, 1>(ra, coef, s_t0, lt_lane);
     double vb = phi_r2<KIND, 1>(rb, coef, s_t0, lt_lane);
     if (KIND == GSL_SINTERP_RBF_TPS) { va = ra > 0.0 ? va : 0.0; vb = rb > 0.0 ? vb : 0.0; }   /* phi(0) = 0 exactly in the matrix */
+    if (SHIFT) {
+      double acca = 0.0, accb = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+        if (a < pk) { acca = fma(pir[r][a], pja[a], acca); accb = fma(pir[r][a], pjb[a], accb); }
+      va = fma(sh, acca, va); vb = fma(sh, accb, vb);
+    }
     double *dst = phi + i * lda + j0;
     /* non-temporal: 1 GB of matrix is written once and read back by the factorisation long after (C3 init 32.66 -> 32.55 ms) */
     if (two && ((((uintptr_t)dst) & 15) == 0)) { typedef double v2d __attribute__((ext_vector_type(2))); v2d vv = {va, vb}; __builtin_nontemporal_store(vv, reinterpret_cast<v2d *>(dst)); }
@@ -538,6 +560,78 @@ static int launch_fill(gsl_sinterp_hip_ctx *ctx, double coef, const double *d_x,
     case 1: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 1>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda, lower_only); break;
     case 2: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 2>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda, lower_only); break;
     default: hipLaunchKernelGGL((rbf_fill_kernel<KIND, 3>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda, lower_only); break;
+  }
+  LAUNCH_CHECK(ctx);
+  return ST_SUCCESS;
+}
+
+#define TN_R 2   /* rows per wave: 8 per workgroup, n / 8 workgroups (16 rows per workgroup left one wave per SIMD: 76 us at N = 4096) */
+/* |Phi|_inf = max_i sum_j |phi(|x_i - x_j|)| from the coordinates (nothing of the matrix is read): TN_R rows per wave, a
+   wave's lanes stride over the columns, fixed summation order (lane partial sums, then the butterfly) -> reproducible */
+template <int DIM>
+__global__ void __launch_bounds__(256)
+tps_rownorm_kernel(double coef, const double *__restrict__ x, size_t n, size_t xtda, unsigned long long *__restrict__ out)
+{
+  __shared__ double s_t0[1];
+  __shared__ __attribute__((aligned(16))) double s_lt[LOG_LDS];        /* the sweep's replicated table: this kernel is VALU / LDS bound */
+  load_tables<LOG_COPIES>(s_t0, s_lt, GSL_SINTERP_RBF_TPS);
+  const double *lt_lane = s_lt + (threadIdx.x & (LOG_COPIES - 1)) * 2;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t ibase = (size_t)blockIdx.x * (4 * TN_R) + (threadIdx.x >> 6) * TN_R;
+  double xi[TN_R][DIM], acc[TN_R];
+#pragma unroll
+  for (int r = 0; r < TN_R; r++) {
+    acc[r] = 0.0;
+#pragma unroll
+    for (int c = 0; c < DIM; c++) xi[r][c] = ibase + r < n ? x[(ibase + r) * xtda + c] : 0.0;
+  }
+#pragma unroll 8
+  for (size_t j = lane; j < n; j += 64) {          /* eight columns' coordinates in flight (one at a time: a load latency per step) */
+    double xj[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; c++) xj[c] = x[j * xtda + c];
+#pragma unroll
+    for (int r = 0; r < TN_R; r++) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < DIM; c++) { const double d = xi[r][c] - xj[c]; r2 = fma(d, d, r2); }
+      const double v = phi_r2<GSL_SINTERP_RBF_TPS, LOG_COPIES>(r2, coef, s_t0, lt_lane);
+      acc[r] += r2 > 0.0 ? fabs(v) : 0.0;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < TN_R; r++) {
+    double a = acc[r];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0 && ibase + r < n) atomicMax(out, (unsigned long long)__double_as_longlong(a));   /* a >= 0: bit order == value order */
+  }
+}
+
+/* thin-plate spline matrix with the shift of the SPD route applied in flight (both triangles): d_norm receives the bit
+   pattern of |Phi|_inf, Pk = k standardised polynomial columns of length n */
+int sinterp_tps_fill_shifted(gsl_sinterp_hip_ctx *ctx, const double *d_x, size_t n, int dim, size_t xtda, double *d_phi, size_t lda,
+                             const double *d_Pk, int k, double cmul, unsigned long long *d_norm)
+{
+  REQUIRE(ctx, dim >= 1 && dim <= 3 && xtda >= (size_t)dim && lda >= n && (n + 15) / 16 <= 65535, ST_EINVAL);
+  int st = ensure_tables(ctx);
+  if (st) return st;
+  const double coef = kernel_coef(GSL_SINTERP_RBF_TPS, 0.0);
+  HIP_OK(ctx, hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx->stream));
+  const dim3 ngrid((unsigned)((n + 4 * TN_R - 1) / (4 * TN_R))), grid((unsigned)((n + 127) / 128), (unsigned)((n + 15) / 16));
+  switch (dim) {
+    case 1:
+      hipLaunchKernelGGL(tps_rownorm_kernel<1>, ngrid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_norm);
+      hipLaunchKernelGGL((rbf_fill_kernel<GSL_SINTERP_RBF_TPS, 1, true>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda, 0, d_Pk, k, cmul, (const unsigned long long *)d_norm);
+      break;
+    case 2:
+      hipLaunchKernelGGL(tps_rownorm_kernel<2>, ngrid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_norm);
+      hipLaunchKernelGGL((rbf_fill_kernel<GSL_SINTERP_RBF_TPS, 2, true>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda, 0, d_Pk, k, cmul, (const unsigned long long *)d_norm);
+      break;
+    default:
+      hipLaunchKernelGGL(tps_rownorm_kernel<3>, ngrid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_norm);
+      hipLaunchKernelGGL((rbf_fill_kernel<GSL_SINTERP_RBF_TPS, 3, true>), grid, dim3(256), 0, ctx->stream, coef, d_x, n, xtda, d_phi, lda, 0, d_Pk, k, cmul, (const unsigned long long *)d_norm);
+      break;
   }
   LAUNCH_CHECK(ctx);
   return ST_SUCCESS;

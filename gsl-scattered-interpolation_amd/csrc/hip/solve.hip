@@ -173,7 +173,11 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
   /* thin-plate spline: the shift and the row norms need the full matrix; Gaussian: the Cholesky reads the lower
      triangle only, the upper one (the "original kept above the diagonal" of cholesky.c:103) only when asked for */
   const bool spd = kind != GSL_SINTERP_RBF_TPS;        /* Gaussian, Wendland: positive definite kernels */
-  int st = sinterp_rbf_fill_ex(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, spd && !keep_upper);
+  static const bool no_fused = getenv("GSL_SINTERP_NO_FUSED_SHIFT") && getenv("GSL_SINTERP_NO_FUSED_SHIFT")[0] == '1';
+  const bool force_lu = getenv("GSL_SINTERP_FORCE_LU") && getenv("GSL_SINTERP_FORCE_LU")[0] == '1';
+  /* thin-plate spline on the SPD route: the matrix is written once, shifted (sinterp_tps_fill_shifted, below) */
+  const bool fused = !spd && !no_fused && !force_lu;
+  int st = fused ? ST_SUCCESS : sinterp_rbf_fill_ex(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda, spd && !keep_upper);
   if (st) return st;
   int info = 0;
 
@@ -187,7 +191,6 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
 
   /* ---- conditionally positive definite kernel: shifted SPD system + Woodbury */
   const int k = dim + 1;
-  const bool force_lu = getenv("GSL_SINTERP_FORCE_LU") && getenv("GSL_SINTERP_FORCE_LU")[0] == '1';
   void *aux = NULL;
   st = sinterp_aux(ctx, ((size_t)(2 * k + 1) * n + 64) * sizeof(double), &aux);
   if (st) return st;
@@ -198,15 +201,21 @@ static int rbf_solve_impl(gsl_sinterp_hip_ctx *ctx, int kind, double eps, const 
 
   double cmul = 4.0;
   for (int attempt = 0; attempt < 2 && !force_lu; attempt++, cmul *= 8.0) {
-    if (attempt > 0) {
+    if (attempt > 0 && !fused) {
       st = gsl_sinterp_hip_rbf_fill(ctx, kind, eps, d_x, n, dim, xtda, d_phi, lda);
       if (st) return st;
     }
     hipLaunchKernelGGL(poly_block_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_x, n, dim, xtda, (const double *)d_w, Y, Pk, G + 24);
-    HIP_OK(ctx, hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const double *)d_phi, lda, n, d_norm);
-    hipLaunchKernelGGL(poly_shift_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, d_phi, lda, n,
-                       (const double *)Pk, k, cmul, (const unsigned long long *)d_norm);
+    if (fused) {
+      /* |Phi|_inf from the coordinates, then Phi + s P P^T written in one pass */
+      st = sinterp_tps_fill_shifted(ctx, d_x, n, dim, xtda, d_phi, lda, Pk, k, cmul, d_norm);
+      if (st) return st;
+    } else {
+      HIP_OK(ctx, hipMemsetAsync(d_norm, 0, sizeof(unsigned long long), ctx->stream));
+      hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const double *)d_phi, lda, n, d_norm);
+      hipLaunchKernelGGL(poly_shift_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, d_phi, lda, n,
+                         (const double *)Pk, k, cmul, (const unsigned long long *)d_norm);
+    }
     LAUNCH_CHECK(ctx);
     st = sinterp_cholesky_factor_solve_sym(ctx, n, d_phi, lda, &info, Y, n, k + 1);   /* the fill (and the shift) write both triangles */
     if (st == ST_EDOM) continue;                  /* not SPD with this shift: larger shift (Y is rebuilt), then LU */

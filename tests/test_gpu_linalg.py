@@ -115,6 +115,41 @@ def test_lu_decomp_and_solve(pkg, orc, n):
     assert np.abs(x - xo).max() <= 1e-7 * np.abs(xo).max()
 
 
+@pytest.mark.parametrize("case", ["ties", "zero_column", "nan_below", "nan_diagonal", "odd_lda"])
+def test_lu_pivot_rule_edge_cases_on_tall_panels(pkg, orc, case):
+    """The pivot rule of lu.c:82-105 on panels tall enough for the cooperative kernel (> 1024 rows): strict '>' (the FIRST row
+    attaining the maximum wins a tie), a NaN below the diagonal never becomes the pivot, a NaN diagonal keeps itself, a zero
+    pivot leaves its column untouched; an odd row stride takes the single-workgroup kernels.  Same permutation as the oracle,
+    same finite entries."""
+    n = 1600
+    rng = np.random.default_rng(7)
+    if case == "ties":
+        a = rng.integers(-3, 4, size=(n, n)).astype(np.float64)          # many equal |a| per column
+        a[np.arange(n), np.arange(n)] += 0.0
+    else:
+        a = rng.standard_normal((n, n))
+    if case == "zero_column":
+        a[:, 70] = 0.0; a[:, 1300] = 0.0
+    if case == "nan_below":
+        a[900, 5] = np.nan; a[1500, 1100] = np.nan
+    if case == "nan_diagonal":
+        a[0, 0] = np.nan
+    lda = n + (1 if case == "odd_lda" else 0)
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_a = torch.zeros((n, lda), dtype=torch.float64, device="cuda")
+    d_a[:, :n] = dev(a)
+    d_p = torch.zeros(n, dtype=torch.int32, device="cuda")
+    signum = ctx.lu_decomp(n, ptr(d_a), lda, ptr(d_p))
+    lu, perm = d_a.cpu().numpy()[:, :n], d_p.cpu().numpy()
+    lu_o, perm_o, sg_o = orc.lu_decomp(a)
+    assert np.array_equal(perm, perm_o.astype(np.int64)) and signum == sg_o
+    fin = np.isfinite(lu_o)
+    assert np.array_equal(np.isfinite(lu), fin)
+    if case in ("ties", "zero_column", "odd_lda"):
+        scale = np.abs(lu_o[fin]).max()
+        assert np.abs(lu[fin] - lu_o[fin]).max() <= 1e-8 * scale
+
+
 def test_lu_singular_reports_edom(pkg):
     ctx = pkg.HipContext.on_torch_stream(0)
     a = np.ones((4, 4))

@@ -20,7 +20,7 @@ LU = ["tests/test_gpu_linalg.py", "-k", "lu_"]
 CASES = [
     ("GSL_SINTERP_NO_GRAPH", LINALG), ("GSL_SINTERP_NO_GRAPH", RBF_INIT),
     ("GSL_SINTERP_NO_STREAMK", LINALG), ("GSL_SINTERP_NO_HYBRID_SK", LINALG), ("GSL_SINTERP_NO_GEMM8", LINALG), ("GSL_SINTERP_NO_GEMM64", LINALG), ("GSL_SINTERP_NO_GEMM_GROUP", LINALG), ("GSL_SINTERP_NO_GEMM_PIPE", LINALG), ("GSL_SINTERP_NO_KN_STREAMK", LINALG),
-    ("GSL_SINTERP_NO_LU_COOP", LU), ("GSL_SINTERP_NO_TRSM64", LU), ("GSL_SINTERP_NO_GRAPH", LU), ("GSL_SINTERP_NO_FOLD", LINALG), ("GSL_SINTERP_NO_FOLD", RBF_INIT),
+    ("GSL_SINTERP_NO_FUSED_SHIFT", RBF_INIT), ("GSL_SINTERP_NO_LU_COOP", LU), ("GSL_SINTERP_NO_TRSM64", LU), ("GSL_SINTERP_NO_GRAPH", LU), ("GSL_SINTERP_NO_FOLD", LINALG), ("GSL_SINTERP_NO_FOLD", RBF_INIT),
     ("GSL_SINTERP_NO_DMA_GEMM", LINALG), ("GSL_SINTERP_NO_PANEL128", LINALG), ("GSL_SINTERP_NO_PANEL128", RBF_INIT),
     ("GSL_SINTERP_NO_DATAFLOW_TRSV", LINALG), ("GSL_SINTERP_NO_DATAFLOW_TRSV", RBF_INIT),
     ("GSL_SINTERP_NO_SORT", RBF_SWEEP), ("GSL_SINTERP_NO_CULL", RBF_SWEEP), ("GSL_SINTERP_SERIAL_CELL_ORDER", RBF_SWEEP),
