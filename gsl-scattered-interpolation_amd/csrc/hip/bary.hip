@@ -1497,22 +1497,24 @@ __device__ __forceinline__ bool leafwalk_target(int n_nodes, const NodeRec *__re
   return safe;
 }
 
-/* LW_SLICES x 256 consecutive targets per workgroup; what the margin test leaves is gathered in LDS and appended to the
-   exact kernel's queue (todo_count / todo) with ONE atomic per workgroup: at ~1 % queued, one atomic per target on the
-   single counter cost more than the walk itself (0.92 ms against 0.4 ms at C5). */
+/* `slices` x 256 consecutive targets per workgroup; what the margin test leaves is gathered in LDS and appended to the exact
+   kernel's queue (todo_count / todo) with ONE atomic per workgroup: at ~1 % queued, one atomic per queued target on the single
+   counter cost more than the walk itself (0.92 ms against 0.4 ms at C5).  slices = 1 by default: with 8 slices (one atomic
+   per 2048 targets) the grid is only 2.4 rounds of resident workgroups and its tail costs more than the atomics save --
+   C5 step 1.231 / 1.185 / 1.158 / 1.148 ms for 8 / 4 / 2 / 1 slices (GSL_SINTERP_LW_SLICES, developer). */
 #define LW_SLICES 8
 __global__ void __launch_bounds__(256)
 leafwalk_kernel(int n_nodes, const NodeRec *__restrict__ rec, const LeafRec *__restrict__ tab, const int *__restrict__ seed, LwGrid g,
                 const unsigned *__restrict__ off, const double *__restrict__ lines, double F, double c0c, double c1c,
                 double s0, double s1, const double *__restrict__ targets, size_t m, size_t ttda, double *__restrict__ values,
-                int *__restrict__ leaf_out, unsigned *__restrict__ todo_count, int *__restrict__ todo, int packed)
+                int *__restrict__ leaf_out, unsigned *__restrict__ todo_count, int *__restrict__ todo, int packed, int slices)
 {
   __shared__ int s_q[LW_SLICES * 256];
   __shared__ unsigned s_nq, s_base;
   if (threadIdx.x == 0) s_nq = 0;
   __syncthreads();
-  for (int sl = 0; sl < LW_SLICES; sl++) {
-    const size_t k = ((size_t)blockIdx.x * LW_SLICES + sl) * 256 + threadIdx.x;
+  for (int sl = 0; sl < slices; sl++) {
+    const size_t k = ((size_t)blockIdx.x * slices + sl) * 256 + threadIdx.x;
     if (k >= m) break;
     const double y0 = targets[k * ttda], y1 = targets[k * ttda + 1];
     if (!leafwalk_target(n_nodes, rec, tab, seed, g, off, lines, F, c0c, c1c, s0, s1, y0, y1, k, values, leaf_out, packed))
@@ -1812,6 +1814,8 @@ static int bary_eval_leafwalk(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void 
   double *vt = via_map ? srt.res1 : srt.vs;
   int *lt = via_map ? (int *)srt.inv : (int *)NULL;
   const int packed = (d_leaf != NULL ? 1 : 0) | (via_map ? 2 : 0);
+  static const int lw_slices_env = getenv("GSL_SINTERP_LW_SLICES") ? atoi(getenv("GSL_SINTERP_LW_SLICES")) : 0;   /* developer: 1 .. 8 */
+  const int lw_slices = lw_slices_env >= 1 && lw_slices_env <= LW_SLICES ? lw_slices_env : 1;
   static const double lwF = getenv("GSL_SINTERP_LW_F") ? atof(getenv("GSL_SINTERP_LW_F")) : 4.0;   /* developer */
   ctx->lw_last = 1;
   LwGrid lg;
@@ -1819,9 +1823,9 @@ static int bary_eval_leafwalk(gsl_sinterp_hip_ctx *ctx, int n_nodes, const void 
   const size_t cells = (size_t)ctx->lw_Gs * ctx->lw_Gs;
   const int *seed = (const int *)((const char *)ctx->d_lw_a + 64);
   const unsigned *off = (const unsigned *)(seed + 2 * cells);
-  hipLaunchKernelGGL(leafwalk_kernel, dim3((unsigned)((m + LW_SLICES * 256 - 1) / (LW_SLICES * 256))), dim3(256), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
+  hipLaunchKernelGGL(leafwalk_kernel, dim3((unsigned)((m + (size_t)lw_slices * 256 - 1) / ((size_t)lw_slices * 256))), dim3(256), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
                      (const LeafRec *)d_leaftab, seed, lg, off, (const double *)ctx->d_lw_lines, lwF, ctx->lw_c[0],
-                     ctx->lw_c[1], h_scale[0], h_scale[1], (const double *)srt.ys, m, (size_t)2, vt, lt, todo_count, todo, packed);
+                     ctx->lw_c[1], h_scale[0], h_scale[1], (const double *)srt.ys, m, (size_t)2, vt, lt, todo_count, todo, packed, lw_slices);
   /* what the margin test (or the walk) left: the reference's arithmetic at every step of the DAG */
   const int *d_jump = have_table ? (const int *)((const char *)ctx->d_jumpt + 64) : (const int *)NULL;
   hipLaunchKernelGGL(bary_eval_kernel<true>, dim3(2048), dim3(256), 0, ctx->stream, n_nodes, (const NodeRec *)d_records,
