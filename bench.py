@@ -517,10 +517,10 @@ def rooflines(cfg, name, n, dim, m_rank, ph, extra=None, gemm=None):
                            "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 6),
                            "traffic": pmc["hbm_traffic_bytes_per_launch"] if pmc and "hbm_traffic_bytes_per_launch" in pmc else None,
                            "traffic_source": pmc["source"] if pmc else None,
-                           "note": "the algorithmic HBM stream is 28 B/target; of the 1.18 ms step 0.35 is the two-level reorder of the "
+                           "note": "the algorithmic HBM stream is 28 B/target; of the ~1.1 ms step 0.35 is the two-level reorder of the "
                                    "targets (five streaming passes, 104 B/target at ~3.3 TB/s), 0.14 the random gather of the un-sort, "
-                                   "0.56 the certified leaf walk (0.38 the walk over the leaves' adjacency from the grid seed: latency of "
-                                   "dependent 64-byte gathers from L2 / Infinity Cache; 0.18 the margin test against the leaf's ~13 lines: "
+                                   "~0.5 the certified leaf walk (the walk over the leaves' adjacency from the grid seed: latency of "
+                                   "dependent 64-byte gathers from L2 / Infinity Cache; the margin test against the leaf's ~13 lines: "
                                    "per-lane load rate), 0.09 the exact DAG kernel on the ~1 % of targets the margin leaves -- not HBM"}
         res["eval_only_mpts"] = round(m_rank / t / 1e6, 3)
         return res

@@ -116,6 +116,8 @@ __device__ __forceinline__ void load_tables(double *s_t0, double *s_lt, int kind
   if (kind == GSL_SINTERP_RBF_GAUSSIAN) {
     for (int i = threadIdx.x; i < TBL_N; i += blockDim.x) s_t0[i] = g_rbf_tables.exp2_frac[i];
   } else {
+    /* eight loads in flight: one at a time, the 16 trips of the replicated table are 16 global round trips (~25 us) per workgroup */
+#pragma unroll 8
     for (int i = threadIdx.x; i < LOG_N * COPIES * 2; i += blockDim.x) s_lt[i] = g_rbf_tables.log_pair[i / (COPIES * 2)][i & 1];
   }
 }
