@@ -150,6 +150,30 @@ def test_lu_pivot_rule_edge_cases_on_tall_panels(pkg, orc, case):
         assert np.abs(lu[fin] - lu_o[fin]).max() <= 1e-8 * scale
 
 
+def test_lu_more_than_sixteen_cooperating_workgroups(pkg):
+    """n = 4400: the first panels are factored by 18 workgroups, so a wave polls its exchange slots in more than one batch.
+    Checked against LAPACK's partial pivoting (scipy: same pivot rule away from ties) and by the residual of P A = L U;
+    the oracle's unblocked sweep would take minutes at this size."""
+    import scipy.linalg
+    n = 4400
+    rng = np.random.default_rng(4400)
+    a = rng.standard_normal((n, n))
+    ctx = pkg.HipContext.on_torch_stream(0)
+    d_a = dev(a)
+    d_p = torch.zeros(n, dtype=torch.int32, device="cuda")
+    signum = ctx.lu_decomp(n, ptr(d_a), n, ptr(d_p))
+    lu, perm = d_a.cpu().numpy(), d_p.cpu().numpy()
+    lu_ref, piv = scipy.linalg.lu_factor(a)
+    perm_ref = np.arange(n)
+    for k, p in enumerate(piv):
+        perm_ref[[k, p]] = perm_ref[[p, k]]
+    assert np.array_equal(perm, perm_ref)
+    assert signum == (-1) ** int(np.count_nonzero(piv != np.arange(n)))
+    assert np.abs(lu - lu_ref).max() <= 1e-9 * np.abs(lu_ref).max()
+    Lm, U = np.tril(lu, -1) + np.eye(n), np.triu(lu)
+    assert np.abs(Lm @ U - a[perm]).max() <= 1e-13 * n * np.abs(a).max()
+
+
 def test_lu_singular_reports_edom(pkg):
     ctx = pkg.HipContext.on_torch_stream(0)
     a = np.ones((4, 4))
