@@ -527,11 +527,25 @@ __device__ __forceinline__ void lc_wave_argmax(double &k, unsigned &p)
   p = (unsigned)__builtin_amdgcn_readlane((int)p, 63);
 }
 
+/* winner of four (key, position) candidates, all eight values loaded before the first comparison (the sequential
+   "if better" form compiled to four dependent LDS round trips with branches in between) */
+__device__ __forceinline__ void lc_pick4(const double *k, const unsigned *p, double &bk, unsigned &bp, int &bw)
+{
+  const double k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
+  const unsigned p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+  const bool b01 = k1 > k0 || (k1 == k0 && p1 < p0);
+  const double ka = b01 ? k1 : k0; const unsigned pa = b01 ? p1 : p0; const int wa = b01 ? 1 : 0;
+  const bool b23 = k3 > k2 || (k3 == k2 && p3 < p2);
+  const double kb = b23 ? k3 : k2; const unsigned pb = b23 ? p3 : p2; const int wb = b23 ? 3 : 2;
+  const bool bb = kb > ka || (kb == ka && pb < pa);
+  bk = bb ? kb : ka; bp = bb ? pb : pa; bw = bb ? wb : wa;
+}
+
 struct LcShared {
   double wrow[4][LC_W];                        /* the four waves' candidate rows */
   double cand[4][LC_W];                        /* after the exchange: each wave's best polled row */
-  double wkey[4], ckey[4];
-  unsigned wpos[4], cpos[4];
+  __attribute__((aligned(16))) double wkey[4], ckey[4];
+  __attribute__((aligned(16))) unsigned wpos[4], cpos[4];
 };
 
 template <int J>
@@ -565,9 +579,8 @@ __device__ __forceinline__ void lc_step(double (&a)[LC_W], unsigned &pos, const 
       LC_TSTAMP(6 * J + 1);
       /* ---- publish the workgroup's candidate: wave 0 the row, wave 1 the header (the other waves go straight to the poll) ---- */
       if (wave < 2) {
-        double bk = sh.wkey[0]; unsigned bp = sh.wpos[0]; int bw = 0;
-#pragma unroll
-        for (int w = 1; w < 4; w++) { const double ok = sh.wkey[w]; const unsigned op = sh.wpos[w]; if (ok > bk || (ok == bk && op < bp)) { bk = ok; bp = op; bw = w; } }
+        double bk; unsigned bp; int bw;
+        lc_pick4(sh.wkey, sh.wpos, bk, bp, bw);
         unsigned long long *slot = slots + ((size_t)(J & 1) * LC_GMAX + bid) * LC_SLOT_WORDS;
         const unsigned long long th = (unsigned long long)tag << 32;
         if (wave == 0) {
@@ -624,9 +637,8 @@ __device__ __forceinline__ void lc_step(double (&a)[LC_W], unsigned &pos, const 
       sh.cand[wave][lane] = grow;
       if (lane == 0) { sh.ckey[wave] = gk; sh.cpos[wave] = gp; }
       __syncthreads();
-      double bk = sh.ckey[0]; unsigned piv = sh.cpos[0]; int bw = 0;
-#pragma unroll
-      for (int w = 1; w < 4; w++) { const double ok = sh.ckey[w]; const unsigned op = sh.cpos[w]; if (ok > bk || (ok == bk && op < piv)) { bk = ok; piv = op; bw = w; } }
+      double bk; unsigned piv; int bw;
+      lc_pick4(sh.ckey, sh.cpos, bk, piv, bw);
       if (piv == 0xffffffffu) piv = c;                      /* cannot happen (the diagonal row is always a candidate) */
       if (bid == 0 && tid == 0) ipiv[c] = (int)piv;
       LC_TSTAMP(6 * J + 4);
